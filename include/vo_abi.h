@@ -1,0 +1,183 @@
+/*
+ * C ABI of the MI355X (gfx950) stereo visual-odometry front-end.
+ *
+ * The reference has no FFI: its boundary is the public method set of `class VOClass`
+ * (reference Include/VOClass.h:62-123), whose five hot-path methods are thin wrappers over one
+ * OpenCV call each.  This header is what a binding of that class binds instead of OpenCV:
+ * every entry point below names the reference method (file:line) whose arithmetic it replaces.
+ * include/VOClass.h is the header-only C++ class with the reference's method names on top of it.
+ *
+ * Conventions
+ *  - plain C, no exceptions, no C++ types; every call returns 0 (VO_OK) or a negative vo_status;
+ *    vo_last_error(ctx) gives the text of the last failure on that context.
+ *  - a context owns one GPU stream and all device buffers; it is used by one thread at a time;
+ *    different contexts are independent.  Nothing is logged.
+ *  - a context processes a BATCH of n independent frame pairs per call (1 <= n <= max_batch);
+ *    the reference's one-pair-at-a-time use is n = 1.  Frame b of a batch is addressed by index b.
+ *  - images are 8-bit grayscale, row-major, `stride` bytes per row, frames of a batch `frame_stride`
+ *    bytes apart.  Points are (x, y) float pairs as cv::Point2f.
+ *  - the library fails (VO_ERR_NO_DEVICE / VO_ERR_HIP) when no gfx950 device or code object is
+ *    available; there is no CPU fallback.
+ */
+#ifndef VO_ABI_H
+#define VO_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct vo_ctx vo_ctx;
+
+typedef struct { float x, y; } vo_point2f;
+typedef struct { float x, y, z; } vo_point3f;
+
+typedef enum {
+    VO_OK = 0,
+    VO_ERR_BAD_ARG = -1,      /* null pointer, size out of range, n > max_batch ... */
+    VO_ERR_BAD_PARAM = -2,    /* parameter combination outside the supported domain */
+    VO_ERR_HIP = -3,          /* a HIP runtime call failed */
+    VO_ERR_NO_DEVICE = -4,
+    VO_ERR_STATE = -5,        /* stage called before the stage that produces its input */
+    VO_ERR_CAPACITY = -6,     /* more features than max_features; results were truncated */
+    VO_ERR_NOT_ENOUGH_POINTS = -7, /* fewer than 4 3D-2D correspondences (OpenCV would throw) */
+    VO_ERR_UNSUPPORTED = -8
+} vo_status;
+
+/* Every literal of the reference's hot path as a run-time field; vo_default_params fills in the
+ * reference's values (Source/VOClass.cpp:13-14,238-254,264,400; Source/VOClassFeatures.cpp:27-28,
+ * 69-70,101-102,172) and OpenCV 4.5.4's defaults for what the reference leaves unset. */
+typedef struct {
+    int width, height;        /* frameW, frameH */
+    int max_batch;            /* frame pairs per call */
+    int max_features;         /* capacity per image; FAST output beyond it is truncated (row-major order) */
+    /* StereoSGBM, MODE_SGBM_3WAY */
+    int min_disparity;        /* 0 (only 0 is supported) */
+    int num_disparities;      /* 96; multiple of 16, <= 256 */
+    int block_size;           /* 11; odd, <= 13 (aggregated cost must fit 14 bits) */
+    int p1, p2;               /* 968, 3872 */
+    int disp12_max_diff;      /* 0 -> 1 */
+    int pre_filter_cap;       /* 0 -> 15 */
+    int uniqueness_ratio;     /* 0 (only 0 is supported) */
+    int wta_simd_lanes;       /* 8: winner-take-all tie rule of OpenCV's 128-bit SIMD loop; 0: scalar rule */
+    /* FAST */
+    int fast_threshold;       /* 20 */
+    int fast_nms;             /* 1 */
+    /* calcOpticalFlowPyrLK */
+    int lk_win;               /* 15 (odd, <= 31) */
+    int lk_max_level;         /* 3 */
+    int lk_max_count;         /* 50 */
+    double lk_epsilon;        /* (double)0.03f */
+    double lk_min_eig;        /* 1e-4 */
+    int loop_threshold;       /* 2 */
+    /* estimateMotion */
+    int depth_thresh;         /* 3000 */
+    int ransac_iters;         /* 100 */
+    float ransac_reproj;      /* 8.0 */
+    double ransac_conf;       /* 0.99 */
+    int ransac_chunk;         /* hypotheses solved on the host and scored on the GPU per round (8) */
+    int host_threads;         /* host worker threads for the minimal solvers of a batch (0 = auto) */
+} vo_params;
+
+typedef struct {
+    int ok;                   /* solvePnPRansac's return value */
+    int iters_run;            /* RANSAC iterations the serial loop would have executed */
+    int best_inliers;
+    int final_from_refine;    /* 1: pose is the final iterative solve on the inliers */
+    int n_features, n_matched, n_object_points;
+} vo_frame_info;
+
+/* fills *p with the reference's literals for a width x height frame, max_batch 1 */
+int vo_default_params(vo_params* p, int width, int height);
+
+/* Context life cycle.  Replaces `VOClass VO;` (Source/main.cpp:9, Source/VOClass.cpp:8-28). */
+int vo_create(const vo_params* p, int device, vo_ctx** out);
+void vo_destroy(vo_ctx* ctx);
+const char* vo_last_error(const vo_ctx* ctx);
+/* last error of a failed vo_create (ctx == NULL there) */
+const char* vo_create_error(void);
+/* stream of the context as a hipStream_t, for callers that time or order work against it */
+void* vo_stream(vo_ctx* ctx);
+int vo_synchronize(vo_ctx* ctx);
+
+/* projectionCL / projectionCR, row-major 3x4.  Replaces the state filled by
+ * VOClass::getProjectionMatrices (Source/VOClass.cpp:102-138). */
+int vo_set_calib(vo_ctx* ctx, const double P0[12], const double P1[12]);
+
+/* imgLT1, imgRT1, imgLT2, imgRT2 of n frame pairs.  Replaces the member images filled by
+ * VOClass::readStereoImagesT1T2 (Source/VOClass.cpp:36-83; Include/VOClass.h:65-66).
+ * Host pointers are copied to the device; device pointers are used in place and must stay valid
+ * until the last stage that reads them has been synchronised. */
+int vo_set_images(vo_ctx* ctx, int n, const uint8_t* lt1, const uint8_t* rt1, const uint8_t* lt2,
+                  const uint8_t* rt2, size_t stride, size_t frame_stride);
+int vo_set_images_device(vo_ctx* ctx, int n, const uint8_t* lt1, const uint8_t* rt1, const uint8_t* lt2,
+                         const uint8_t* rt2, size_t stride, size_t frame_stride);
+
+/* VOClass::computeDisparity(imgLT1, imgRT1) (Source/VOClass.cpp:231-305): StereoSGBM 3-way + median,
+ * s16 x16 map and its /16 float form, for all n frames. */
+int vo_compute_disparity(vo_ctx* ctx);
+int vo_get_disparity16(vo_ctx* ctx, int b, int16_t* out /* H*W */);
+int vo_get_disparity32(vo_ctx* ctx, int b, float* out /* H*W */);
+
+/* VOClass::computeDepthMap (Source/VOClass.cpp:312-366): patches the float disparity in place
+ * (0 and -1 become 0.1f) and produces the f64 depth map. */
+int vo_compute_depth_map(vo_ctx* ctx);
+int vo_get_depth(vo_ctx* ctx, int b, double* out /* H*W */);
+
+/* VOClass::getFeaturesFAST(imgLT1) (Source/VOClassFeatures.cpp:7-39). */
+int vo_detect_fast(vo_ctx* ctx);
+int vo_get_features(vo_ctx* ctx, int b, vo_point2f* out, int cap, int* n_out);
+/* caller-supplied feature list for frame b (the vector argument of matchFeatureKLT) */
+int vo_set_features(vo_ctx* ctx, int b, const vo_point2f* pts, int n);
+
+/* VOClass::matchFeatureKLT (Source/VOClassFeatures.cpp:54-202): four pyramidal LK legs
+ * LT1->RT1->RT2->LT2->LT1, bounds filter, 4-way status AND, loop-closure test.
+ * t1 receives the re-tracked LT1 points (the reference overwrites its in/out argument with them),
+ * t2 the matching LT2 points. */
+int vo_match_klt(vo_ctx* ctx);
+int vo_get_matches(vo_ctx* ctx, int b, vo_point2f* t1, vo_point2f* t2, int cap, int* m_out);
+/* per-leg end points (4 x n) and status bytes after the bounds filter (4 x n); n = feature count */
+int vo_get_klt_legs(vo_ctx* ctx, int b, vo_point2f* pts /* 4*n */, uint8_t* status /* 4*n */, int n);
+int vo_set_matches(vo_ctx* ctx, int b, const vo_point2f* t1, const vo_point2f* t2, int m);
+
+/* VOClass::estimateMotion part 1 (Source/VOClass.cpp:396-441): depth look-up, depth filter,
+ * back-projection.  Uses the depth map if vo_compute_depth_map ran, else derives depth from the
+ * disparity on the fly (same values). */
+int vo_triangulate(vo_ctx* ctx);
+int vo_get_object_points(vo_ctx* ctx, int b, vo_point3f* obj, vo_point2f* img2, int cap, int* k_out);
+
+/* Scoring step of cv::solvePnPRansac (Source/VOClass.cpp:531): reprojection error of every
+ * correspondence of frame b under H hypotheses (R row-major 3x3 then t: 12 doubles each), inlier
+ * iff squared error <= thresh2.  counts: H ints; masks nullable: H * k bytes. */
+int vo_pnp_score(vo_ctx* ctx, int b, const double* Rt12, int H, float thresh2, int* counts, uint8_t* masks);
+
+/* VOClass::estimateMotion parts 2 and 3 (Source/VOClass.cpp:531-599) for all n frames:
+ * RANSAC (host minimal solver + GPU scoring), final iterative solve, Rodrigues, Rt.
+ * Rt_out: n x 16 doubles (row-major 4x4 [R|t; 0 0 0 1]); the caller integrates
+ * pose = pose * inv(Rt) (vo_integrate_pose). */
+int vo_estimate_motion(vo_ctx* ctx, double* Rt_out, vo_frame_info* info /* nullable, n */);
+/* poseRt = poseRt * Rt.inv() (Source/VOClass.cpp:587), 4x4 row-major f64, LU inverse */
+int vo_integrate_pose(double pose_inout[16], const double Rt[16]);
+
+/* One iteration of Source/main.cpp:36-60 for n frame pairs, images already set:
+ * disparity, FAST, circular KLT, triangulation, PnP.  Same results as the stage calls in sequence. */
+int vo_step(vo_ctx* ctx, double* Rt_out /* n*16 */, vo_frame_info* info /* nullable, n */);
+
+/* Test taps: intermediate buffers of frame b copied to the host. */
+typedef enum {
+    VO_TAP_FAST_SCORE = 1,     /* u8 H*W */
+    VO_TAP_DISP_PREMEDIAN = 2, /* s16 H*W */
+    VO_TAP_COST_ROW = 3,       /* s16 width1*D: aggregated cost, arg0 = stripe, arg1 = image row */
+    VO_TAP_PYR_LEVEL = 4,      /* u8 h*w of pyramid level arg1 of image arg0 (0 LT1, 1 RT1, 2 RT2, 3 LT2) */
+    VO_TAP_DERIV_LEVEL = 5     /* s16 h*w*2 Scharr derivative of the same */
+} vo_tap;
+int vo_read_tap(vo_ctx* ctx, int tap, int b, int arg0, int arg1, void* out, size_t bytes);
+/* size in pixels of pyramid level `level`, and the number of levels built (maxLevel) */
+int vo_pyramid_info(vo_ctx* ctx, int level, int* w, int* h, int* max_level);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

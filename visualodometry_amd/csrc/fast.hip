@@ -1,0 +1,187 @@
+// FAST-9/16 corner detector with 3x3 non-max suppression and row-major ordered compaction (gfx950).
+// Replaces cv::FAST(img, keypoints, threshold, true) + KeyPoint::convert as used by
+// VOClass::getFeaturesFAST (reference Source/VOClassFeatures.cpp:27-32).
+//
+//  fast_score_kernel  : one thread per pixel, 64x16 tile (+3 halo) staged in LDS; the 16 ring pixels are
+//                       turned into a bright and a dark 16-bit mask, "9 contiguous" is a shift-and-AND test,
+//                       the corner score is the closed form max(t, max_arc min(d), max_arc min(-d)) - 1.
+//  fast_count_kernel  : per image row, number of pixels whose score is a strict 3x3 maximum.
+//  fast_scan_kernel   : exclusive scan of the row counts (one block per image).
+//  fast_write_kernel  : per image row, wavefront ballot + prefix popcount gives every keypoint its rank,
+//                       so the output order is y-major, x-minor, identical on every run.
+#include "vo_ctx.h"
+#include <string.h>
+#include <algorithm>
+
+namespace {
+
+constexpr int TILE_W = 64, TILE_H = 16, HALO = 3;
+constexpr int LDS_W = TILE_W + 2 * HALO + 2; // 72
+constexpr int LDS_H = TILE_H + 2 * HALO;     // 22
+
+__device__ __forceinline__ int sliding_min9_max(const int d[16])
+{
+    // max over the 16 circular arcs of length 9 of the arc minimum
+    int m2[16], m4[16], m8[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) m2[i] = min(d[i], d[(i + 1) & 15]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) m4[i] = min(m2[i], m2[(i + 2) & 15]);
+#pragma unroll
+    for (int i = 0; i < 16; i++) m8[i] = min(m4[i], m4[(i + 4) & 15]);
+    int best = -1000;
+#pragma unroll
+    for (int i = 0; i < 16; i++) best = max(best, min(m8[i], d[(i + 8) & 15]));
+    return best;
+}
+
+__global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restrict__ img, size_t pitch, size_t fstride,
+                                                         int W, int H, int thr, int nms, uint8_t* __restrict__ score)
+{
+    __shared__ uint8_t tile[LDS_H][LDS_W];
+    const int b = blockIdx.z;
+    const uint8_t* src = img + (size_t)b * fstride;
+    const int x0 = blockIdx.x * TILE_W - HALO, y0 = blockIdx.y * TILE_H - HALO;
+    const int tid = threadIdx.y * TILE_W + threadIdx.x;
+    for (int i = tid; i < LDS_H * (TILE_W + 2 * HALO); i += 256) {
+        int ty = i / (TILE_W + 2 * HALO), tx = i - ty * (TILE_W + 2 * HALO);
+        int gx = x0 + tx, gy = y0 + ty;
+        uint8_t v = 0;
+        if (gx >= 0 && gx < W && gy >= 0 && gy < H) v = src[(size_t)gy * pitch + gx];
+        tile[ty][tx] = v;
+    }
+    __syncthreads();
+    const int x = blockIdx.x * TILE_W + threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < TILE_H / 4; r++) {
+        const int ly = threadIdx.y + r * 4;
+        const int y = blockIdx.y * TILE_H + ly;
+        if (x >= W || y >= H) continue;
+        uint8_t out = 0;
+        if (x >= 3 && x < W - 3 && y >= 3 && y < H - 3) {
+            const int cx = threadIdx.x + HALO, cy = ly + HALO;
+            const int v = tile[cy][cx];
+            int ring[16];
+            ring[0] = tile[cy + 3][cx];      ring[1] = tile[cy + 3][cx + 1];  ring[2] = tile[cy + 2][cx + 2];
+            ring[3] = tile[cy + 1][cx + 3];  ring[4] = tile[cy][cx + 3];      ring[5] = tile[cy - 1][cx + 3];
+            ring[6] = tile[cy - 2][cx + 2];  ring[7] = tile[cy - 3][cx + 1];  ring[8] = tile[cy - 3][cx];
+            ring[9] = tile[cy - 3][cx - 1];  ring[10] = tile[cy - 2][cx - 2]; ring[11] = tile[cy - 1][cx - 3];
+            ring[12] = tile[cy][cx - 3];     ring[13] = tile[cy + 1][cx - 3]; ring[14] = tile[cy + 2][cx - 2];
+            ring[15] = tile[cy + 3][cx - 1];
+            unsigned dark = 0, bright = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                dark |= (unsigned)(ring[k] < v - thr) << k;
+                bright |= (unsigned)(ring[k] > v + thr) << k;
+            }
+            auto arc9 = [](unsigned m) {
+                unsigned mm = m | (m << 16);
+                unsigned t = mm & (mm >> 1);
+                t &= t >> 2;
+                t &= t >> 4;
+                t &= mm >> 8;
+                return (t & 0xffffu) != 0;
+            };
+            if (arc9(dark) || arc9(bright)) {
+                if (nms) {
+                    int d[16], e[16];
+#pragma unroll
+                    for (int k = 0; k < 16; k++) { d[k] = v - ring[k]; e[k] = -d[k]; }
+                    int a = sliding_min9_max(d), bm = sliding_min9_max(e);
+                    out = (uint8_t)(max(thr, max(a, bm)) - 1);
+                } else out = 1;
+            }
+        }
+        score[((size_t)b * H + y) * W + x] = out;
+    }
+}
+
+__device__ __forceinline__ bool is_keypoint(const uint8_t* __restrict__ s, int W, int x, int y, int nms)
+{
+    // rows 0 and H-1, columns 0 and W-1 never hold a score, so the 3x3 reads stay inside for every scored pixel
+    const uint8_t* p = s + (size_t)y * W + x;
+    int v = p[0];
+    if (v == 0) return false;
+    if (!nms) return true;
+    return v > p[-1] && v > p[1] && v > p[-W - 1] && v > p[-W] && v > p[-W + 1] && v > p[W - 1] && v > p[W] && v > p[W + 1];
+}
+
+__global__ __launch_bounds__(256) void fast_count_kernel(const uint8_t* __restrict__ score, int W, int H, int nms, int* __restrict__ row_count)
+{
+    __shared__ int wsum[4];
+    const int y = blockIdx.x, b = blockIdx.y;
+    const uint8_t* s = score + (size_t)b * H * W;
+    int cnt = 0;
+    if (y >= 3 && y < H - 3)
+        for (int x = 3 + threadIdx.x; x < W - 3; x += 256) cnt += is_keypoint(s, W, x, y, nms);
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) row_count[b * H + y] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void fast_scan_kernel(const int* __restrict__ row_count, int H, int cap,
+                                                        int* __restrict__ row_off, int* __restrict__ n_feat)
+{
+    __shared__ int part[256];
+    const int b = blockIdx.x;
+    const int per = (H + 255) / 256;
+    const int y0 = threadIdx.x * per, y1 = min(y0 + per, H);
+    int s = 0;
+    for (int y = y0; y < y1; y++) s += row_count[b * H + y];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int i = 0; i < 256; i++) { int t = part[i]; part[i] = acc; acc += t; }
+        n_feat[b] = min(acc, cap);
+    }
+    __syncthreads();
+    int acc = part[threadIdx.x];
+    for (int y = y0; y < y1; y++) { row_off[b * H + y] = acc; acc += row_count[b * H + y]; }
+}
+
+__global__ __launch_bounds__(256) void fast_write_kernel(const uint8_t* __restrict__ score, int W, int H, int nms, int cap,
+                                                         const int* __restrict__ row_count, const int* __restrict__ row_off,
+                                                         vo_point2f* __restrict__ feat)
+{
+    __shared__ int wcnt[4];
+    const int y = blockIdx.x, b = blockIdx.y;
+    if (row_count[b * H + y] == 0) return; // uniform per block
+    const uint8_t* s = score + (size_t)b * H * W;
+    vo_point2f* out = feat + (size_t)b * cap;
+    int base = row_off[b * H + y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int xs = 3; xs < W - 3; xs += 256) {
+        int x = xs + threadIdx.x;
+        bool k = x < W - 3 && is_keypoint(s, W, x, y, nms);
+        unsigned long long m = __ballot(k);
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; w++) before += wcnt[w];
+        int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        if (k) {
+            int rank = base + before + __popcll(m & ((1ull << lane) - 1ull));
+            if (rank < cap) { out[rank].x = (float)x; out[rank].y = (float)y; }
+        }
+        base += total;
+        __syncthreads();
+    }
+}
+
+} // namespace
+
+int launch_fast(vo_ctx* c)
+{
+    const int W = c->W, H = c->H, n = c->n;
+    dim3 g1((W + TILE_W - 1) / TILE_W, (H + TILE_H - 1) / TILE_H, n), b1(TILE_W, 4);
+    hipLaunchKernelGGL(fast_score_kernel, g1, b1, 0, c->stream, c->img[0], c->pitch, c->fstride, W, H,
+                       c->p.fast_threshold, c->p.fast_nms, c->score);
+    hipLaunchKernelGGL(fast_count_kernel, dim3(H, n), dim3(256), 0, c->stream, c->score, W, H, c->p.fast_nms, c->row_count);
+    hipLaunchKernelGGL(fast_scan_kernel, dim3(n), dim3(256), 0, c->stream, c->row_count, H, c->p.max_features, c->row_off, c->n_feat);
+    hipLaunchKernelGGL(fast_write_kernel, dim3(H, n), dim3(256), 0, c->stream, c->score, W, H, c->p.fast_nms,
+                       c->p.max_features, c->row_count, c->row_off, c->feat);
+    VO_HIP(c, hipGetLastError());
+    return VO_OK;
+}

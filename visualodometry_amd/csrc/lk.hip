@@ -1,0 +1,359 @@
+// Image pyramids, Scharr derivatives, pyramidal Lucas-Kanade and the circular-match filter for gfx950.
+// Replaces the four cv::calcOpticalFlowPyrLK calls and the filtering of VOClass::matchFeatureKLT
+// (reference Source/VOClassFeatures.cpp:104-111,134-201; Source/VOClassUtils.cpp:61-78).
+//
+// Storage: every pyramid level is kept with a REFLECT_101 border of lk_win pixels (what
+// buildOpticalFlowPyramid keeps), its Scharr derivative (Ix, Iy int16 pairs) with a zero border of the same
+// width, so the tracker never branches on image edges.
+//
+//  level0_kernel   : copies an input image into its bordered level-0 slot.
+//  pyrdown_kernel  : separable 5-tap [1 4 6 4 1] in LDS: horizontal sums of a source strip, then vertical,
+//                    (sum + 128) >> 8; reads the bordered previous level, so no edge cases.
+//  border_kernel   : fills the border of a level by reflection.
+//  scharr_kernel   : 3x3 Scharr of a level (from its bordered image), zero outside.
+//  lk_kernel       : one wavefront per feature runs all four legs LT1->RT1->RT2->LT2->LT1 and all pyramid
+//                    levels; the win x win window is spread over the 64 lanes, the 2x2 structure tensor and
+//                    the mismatch vector are accumulated in integers (order independent) and reduced with DPP
+//                    row adds + readlane; the 2x2 solve is replicated per lane in f32 without contraction.
+//  filter_kernel   : bounds filter per leg, 4-way status AND, loop-closure test, ordered compaction.
+#include "vo_ctx.h"
+#include <string.h>
+#include <algorithm>
+
+namespace {
+
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
+}
+
+struct LevelArgs { int w, h, pitch, rows; unsigned img_off, der_off; };
+struct PyrArgs { int nlevels, border; LevelArgs lv[VO_MAX_LEVELS]; unsigned long long pyr_bytes, der_elems; };
+
+__global__ __launch_bounds__(256) void level0_kernel(const uint8_t* i0, const uint8_t* i1, const uint8_t* i2, const uint8_t* i3,
+                                                     size_t pitch, size_t fstride, PyrArgs pa, uint8_t* __restrict__ pyr)
+{
+    const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y;
+    const int b = blockIdx.z >> 2, which = blockIdx.z & 3;
+    const LevelArgs L = pa.lv[0];
+    if (px >= L.pitch) return;
+    const uint8_t* src = (which == 0 ? i0 : which == 1 ? i1 : which == 2 ? i2 : i3) + (size_t)b * fstride;
+    int x = reflect101(min(px, L.w + 2 * pa.border - 1) - pa.border, L.w), y = reflect101(py - pa.border, L.h);
+    pyr[((size_t)b * 4 + which) * pa.pyr_bytes + L.img_off + (size_t)py * L.pitch + px] = src[(size_t)y * pitch + x];
+}
+
+constexpr int PD_TX = 32, PD_TY = 8;
+
+__global__ __launch_bounds__(256) void pyrdown_kernel(PyrArgs pa, int level, uint8_t* __restrict__ pyr)
+{
+    __shared__ int hs[2 * PD_TY + 3][PD_TX];
+    const LevelArgs S = pa.lv[level - 1], Dl = pa.lv[level];
+    uint8_t* base = pyr + (size_t)blockIdx.z * pa.pyr_bytes;
+    const uint8_t* src = base + S.img_off + (size_t)pa.border * S.pitch + pa.border; // interior origin
+    uint8_t* dst = base + Dl.img_off + (size_t)pa.border * Dl.pitch + pa.border;
+    const int x0 = blockIdx.x * PD_TX, y0 = blockIdx.y * PD_TY;
+    const int tx = threadIdx.x & (PD_TX - 1), ty = threadIdx.x / PD_TX; // 32 x 8
+    const int x = x0 + tx;
+    // horizontal pass over source rows 2*y0-2 .. 2*y0+2*PD_TY (19 rows); rows/cols outside the level come from its border
+    for (int r = ty; r < 2 * PD_TY + 3; r += PD_TY) {
+        int sy = min(2 * y0 - 2 + r, S.h + 1); // rows beyond h+1 are never used by a valid output row
+        int sx = min(2 * x, S.w + 1);
+        const uint8_t* p = src + (ptrdiff_t)sy * S.pitch + sx;
+        hs[r][tx] = p[-2] + 4 * p[-1] + 6 * p[0] + 4 * p[1] + p[2];
+    }
+    __syncthreads();
+    const int y = y0 + ty;
+    if (x < Dl.w && y < Dl.h) {
+        int r = 2 * ty;
+        int s = hs[r][tx] + 4 * hs[r + 1][tx] + 6 * hs[r + 2][tx] + 4 * hs[r + 3][tx] + hs[r + 4][tx];
+        dst[(size_t)y * Dl.pitch + x] = (uint8_t)((s + 128) >> 8);
+    }
+}
+
+__global__ __launch_bounds__(256) void border_kernel(PyrArgs pa, int level, uint8_t* __restrict__ pyr)
+{
+    const LevelArgs L = pa.lv[level];
+    const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y;
+    if (px >= L.pitch) return;
+    const int x = px - pa.border, y = py - pa.border;
+    if (x >= 0 && x < L.w && y >= 0 && y < L.h) return;
+    uint8_t* img = pyr + (size_t)blockIdx.z * pa.pyr_bytes + L.img_off;
+    int sx = reflect101(min(x, L.w + pa.border - 1), L.w), sy = reflect101(y, L.h);
+    img[(size_t)py * L.pitch + px] = img[(size_t)(sy + pa.border) * L.pitch + sx + pa.border];
+}
+
+__global__ __launch_bounds__(256) void scharr_kernel(PyrArgs pa, int level, const uint8_t* __restrict__ pyr, int16_t* __restrict__ der)
+{
+    const LevelArgs L = pa.lv[level];
+    const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y;
+    if (px >= L.pitch) return;
+    const int x = px - pa.border, y = py - pa.border;
+    int ix = 0, iy = 0;
+    if (x >= 0 && x < L.w && y >= 0 && y < L.h) {
+        const uint8_t* p = pyr + (size_t)blockIdx.z * pa.pyr_bytes + L.img_off + (size_t)py * L.pitch + px;
+        const int P = L.pitch;
+        int a00 = p[-P - 1], a01 = p[-P], a02 = p[-P + 1];
+        int a10 = p[-1], a12 = p[1];
+        int a20 = p[P - 1], a21 = p[P], a22 = p[P + 1];
+        ix = ((a02 + a22) * 3 + a12 * 10) - ((a00 + a20) * 3 + a10 * 10);
+        iy = ((a20 - a00) + (a22 - a02)) * 3 + (a21 - a01) * 10;
+    }
+    int* out = reinterpret_cast<int*>(der + (size_t)blockIdx.z * pa.der_elems + L.der_off);
+    out[(size_t)py * L.pitch + px] = (ix & 0xffff) | (iy << 16);
+}
+
+// ---------------------------------------------------------------- tracker
+#define DPP_ADD(v, ctrl) ((v) + __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, false))
+// exact 64-lane sum of per-lane int32 values, as int64, identical in every lane
+__device__ __forceinline__ long long wave_sum(int v)
+{
+    int lo = v & 0xffff, hi = v >> 16;
+    lo = DPP_ADD(lo, 0xB1); lo = DPP_ADD(lo, 0x4E); lo = DPP_ADD(lo, 0x141); lo = DPP_ADD(lo, 0x140);
+    hi = DPP_ADD(hi, 0xB1); hi = DPP_ADD(hi, 0x4E); hi = DPP_ADD(hi, 0x141); hi = DPP_ADD(hi, 0x140);
+    int slo = __builtin_amdgcn_readlane(lo, 0) + __builtin_amdgcn_readlane(lo, 16) + __builtin_amdgcn_readlane(lo, 32) + __builtin_amdgcn_readlane(lo, 48);
+    int shi = __builtin_amdgcn_readlane(hi, 0) + __builtin_amdgcn_readlane(hi, 16) + __builtin_amdgcn_readlane(hi, 32) + __builtin_amdgcn_readlane(hi, 48);
+    return ((long long)shi << 16) + (long long)slo;
+}
+
+__device__ __forceinline__ int cv_floor(float v) { return (int)floorf(v); }
+__device__ __forceinline__ int cv_round(float v) { return __float2int_rn(v); }
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+struct LkArgs {
+    PyrArgs pa;
+    int win, max_count, max_features;
+    float min_eig;
+    double eps2;
+};
+
+__device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int& w01, int& w10, int& w11)
+{
+    w00 = cv_round((1.f - a) * (1.f - b) * (float)(1 << 14));
+    w01 = cv_round(a * (1.f - b) * (float)(1 << 14));
+    w10 = cv_round((1.f - a) * b * (float)(1 << 14));
+    w11 = (1 << 14) - w00 - w01 - w10;
+}
+
+// NPL = ceil(win*win / 64): window pixels per lane
+template <int NPL>
+__global__ __launch_bounds__(256) void lk_kernel(LkArgs a, const uint8_t* __restrict__ pyr, const int16_t* __restrict__ der,
+                                                 const vo_point2f* __restrict__ feat, const int* __restrict__ n_feat,
+                                                 vo_point2f* __restrict__ legs, uint8_t* __restrict__ leg_status)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (i >= n_feat[b]) return; // uniform per wavefront
+    const int win = a.win, area = win * win;
+    const float half = (win - 1) * 0.5f;
+    int wx[NPL], wy[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; k++) {
+        int p = min(lane + 64 * k, area - 1);
+        wy[k] = p / win; wx[k] = p - wy[k] * win;
+    }
+    // legs: LT1->RT1, RT1->RT2, RT2->LT2, LT2->LT1 with image slots 0 LT1, 1 RT1, 2 LT2, 3 RT2
+    const int leg_prev[4] = {0, 1, 3, 2}, leg_next[4] = {1, 3, 2, 0};
+    vo_point2f prev0 = feat[(size_t)b * a.max_features + i];
+    const int nl = a.pa.nlevels;
+
+    for (int leg = 0; leg < 4; leg++) {
+        const uint8_t* Ibase = pyr + ((size_t)b * 4 + leg_prev[leg]) * a.pa.pyr_bytes;
+        const uint8_t* Jbase = pyr + ((size_t)b * 4 + leg_next[leg]) * a.pa.pyr_bytes;
+        const int16_t* Dbase = der + ((size_t)b * 4 + leg_prev[leg]) * a.pa.der_elems;
+        float nx = 0.f, ny = 0.f; // nextPts entry
+        int status = 1;
+        for (int level = nl; level >= 0; level--) {
+            const LevelArgs L = a.pa.lv[level];
+            const float sc = 1.f / (float)(1 << level);
+            float px = prev0.x * sc, py = prev0.y * sc;
+            float qx, qy;
+            if (level == nl) { qx = px; qy = py; }
+            else { qx = nx * 2.f; qy = ny * 2.f; }
+            nx = qx; ny = qy;
+            px -= half; py -= half;
+            const int ipx = cv_floor(px), ipy = cv_floor(py);
+            if (ipx < -win || ipx >= L.w || ipy < -win || ipy >= L.h) {
+                if (level == 0) status = 0;
+                continue;
+            }
+            int w00, w01, w10, w11;
+            bilinear_weights(px - ipx, py - ipy, w00, w01, w10, w11);
+            const int P = L.pitch;
+            const uint8_t* I = Ibase + L.img_off + (size_t)(ipy + a.pa.border) * P + (ipx + a.pa.border);
+            const int* Dv = reinterpret_cast<const int*>(Dbase + L.der_off) + (size_t)(ipy + a.pa.border) * P + (ipx + a.pa.border);
+            int Iv[NPL], Ix[NPL], Iy[NPL];
+            int s11 = 0, s12 = 0, s22 = 0;
+#pragma unroll
+            for (int k = 0; k < NPL; k++) {
+                const bool on = lane + 64 * k < area;
+                const uint8_t* s = I + wy[k] * P + wx[k];
+                const int* d = Dv + wy[k] * P + wx[k];
+                int iv = descale(s[0] * w00 + s[1] * w01 + s[P] * w10 + s[P + 1] * w11, 14 - 5);
+                int d00 = d[0], d01 = d[1], d10 = d[P], d11 = d[P + 1];
+                int ixv = descale((short)d00 * w00 + (short)d01 * w01 + (short)d10 * w10 + (short)d11 * w11, 14);
+                int iyv = descale((d00 >> 16) * w00 + (d01 >> 16) * w01 + (d10 >> 16) * w10 + (d11 >> 16) * w11, 14);
+                if (!on) { iv = 0; ixv = 0; iyv = 0; }
+                Iv[k] = iv; Ix[k] = ixv; Iy[k] = iyv;
+                s11 += ixv * ixv; s12 += ixv * iyv; s22 += iyv * iyv;
+            }
+            const float FLT_SCALE = 1.f / (float)(1 << 20);
+            const float A11 = (float)wave_sum(s11) * FLT_SCALE, A12 = (float)wave_sum(s12) * FLT_SCALE, A22 = (float)wave_sum(s22) * FLT_SCALE;
+            float Dt = A11 * A22 - A12 * A12;
+            const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
+            if (minEig < a.min_eig || Dt < 1.1920929e-07f) {
+                if (level == 0) status = 0;
+                continue;
+            }
+            Dt = 1.f / Dt;
+            qx -= half; qy -= half;
+            float pdx = 0.f, pdy = 0.f;
+            const uint8_t* Jl = Jbase + L.img_off + (size_t)a.pa.border * P + a.pa.border;
+            for (int j = 0; j < a.max_count; j++) {
+                const int inx = cv_floor(qx), iny = cv_floor(qy);
+                if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) {
+                    if (level == 0) status = 0;
+                    break;
+                }
+                bilinear_weights(qx - inx, qy - iny, w00, w01, w10, w11);
+                const uint8_t* J = Jl + (ptrdiff_t)iny * P + inx;
+                int sb1 = 0, sb2 = 0;
+#pragma unroll
+                for (int k = 0; k < NPL; k++) {
+                    const uint8_t* s = J + wy[k] * P + wx[k];
+                    int diff = descale(s[0] * w00 + s[1] * w01 + s[P] * w10 + s[P + 1] * w11, 14 - 5) - Iv[k];
+                    sb1 += diff * Ix[k]; sb2 += diff * Iy[k]; // Ix = Iy = 0 on lanes past the window
+                }
+                const float b1 = (float)wave_sum(sb1) * FLT_SCALE, b2 = (float)wave_sum(sb2) * FLT_SCALE;
+                const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
+                qx += dx; qy += dy;
+                nx = qx + half; ny = qy + half;
+                if ((double)dx * (double)dx + (double)dy * (double)dy <= a.eps2) break;
+                if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+                    nx -= dx * 0.5f; ny -= dy * 0.5f;
+                    break;
+                }
+                pdx = dx; pdy = dy;
+            }
+            if (status && level == 0) {
+                // the error pass of the original re-tests the final window position and can clear the status
+                const int inx = cv_floor(nx - half), iny = cv_floor(ny - half);
+                if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) status = 0;
+            }
+        }
+        if (lane == 0) {
+            vo_point2f o; o.x = nx; o.y = ny;
+            legs[((size_t)b * 4 + leg) * a.max_features + i] = o;
+            leg_status[((size_t)b * 4 + leg) * a.max_features + i] = (uint8_t)status;
+        }
+        prev0.x = nx; prev0.y = ny;
+    }
+}
+
+// ---------------------------------------------------------------- circular-match filter
+__global__ __launch_bounds__(256) void filter_kernel(const vo_point2f* __restrict__ feat, const int* __restrict__ n_feat, int max_features,
+                                                     float fw, float fh, int loop_thr, const vo_point2f* __restrict__ legs,
+                                                     uint8_t* __restrict__ leg_status, vo_point2f* __restrict__ m1, vo_point2f* __restrict__ m2,
+                                                     int* __restrict__ n_match)
+{
+    __shared__ int wcnt[4];
+    const int b = blockIdx.x, n = n_feat[b];
+    const size_t F = max_features;
+    const vo_point2f* f0 = feat + (size_t)b * F;
+    const vo_point2f* lg = legs + (size_t)b * 4 * F;
+    uint8_t* st = leg_status + (size_t)b * 4 * F;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        bool keep = false;
+        vo_point2f p3 = {0.f, 0.f}, p2 = {0.f, 0.f};
+        if (i < n) {
+            int ok = 1;
+#pragma unroll
+            for (int leg = 0; leg < 4; leg++) {
+                vo_point2f q = lg[(size_t)leg * F + i];
+                int s = st[(size_t)leg * F + i];
+                if (q.x < 0.f || q.x > fw || q.y < 0.f || q.y > fh) { s = 0; st[(size_t)leg * F + i] = 0; }
+                ok &= (s == 1);
+                if (leg == 2) p2 = q;
+                if (leg == 3) p3 = q;
+            }
+            vo_point2f o = f0[i];
+            int offset = (int)fmaxf(fabsf(o.x - p3.x), fabsf(o.y - p3.y));
+            keep = ok && offset < loop_thr;
+        }
+        unsigned long long mk = __ballot(keep);
+        if (lane == 0) wcnt[wave] = __popcll(mk);
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; w++) before += wcnt[w];
+        const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        if (keep) {
+            int r = base + before + __popcll(mk & ((1ull << lane) - 1ull));
+            m1[(size_t)b * F + r] = p3;
+            m2[(size_t)b * F + r] = p2;
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n_match[b] = base;
+}
+
+} // namespace
+
+static PyrArgs make_pyr_args(const vo_ctx* c)
+{
+    PyrArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    pa.nlevels = c->nlevels; pa.border = c->border; pa.pyr_bytes = c->pyr_bytes; pa.der_elems = c->der_elems;
+    for (int l = 0; l <= c->nlevels; l++) {
+        pa.lv[l].w = c->lv[l].w; pa.lv[l].h = c->lv[l].h; pa.lv[l].pitch = c->lv[l].pitch; pa.lv[l].rows = c->lv[l].rows;
+        pa.lv[l].img_off = (unsigned)c->lv[l].img_off; pa.lv[l].der_off = (unsigned)c->lv[l].der_off;
+    }
+    return pa;
+}
+
+int launch_pyramids(vo_ctx* c)
+{
+    const PyrArgs pa = make_pyr_args(c);
+    const int nimg = 4 * c->n;
+    hipLaunchKernelGGL(level0_kernel, dim3((pa.lv[0].pitch + 255) / 256, pa.lv[0].rows, nimg), dim3(256), 0, c->stream,
+                       c->img[0], c->img[1], c->img[2], c->img[3], c->pitch, c->fstride, pa, c->pyr);
+    for (int l = 1; l <= c->nlevels; l++) {
+        hipLaunchKernelGGL(pyrdown_kernel, dim3((pa.lv[l].w + PD_TX - 1) / PD_TX, (pa.lv[l].h + PD_TY - 1) / PD_TY, nimg), dim3(256), 0,
+                           c->stream, pa, l, c->pyr);
+        hipLaunchKernelGGL(border_kernel, dim3((pa.lv[l].pitch + 255) / 256, pa.lv[l].rows, nimg), dim3(256), 0, c->stream, pa, l, c->pyr);
+    }
+    for (int l = 0; l <= c->nlevels; l++)
+        hipLaunchKernelGGL(scharr_kernel, dim3((pa.lv[l].pitch + 255) / 256, pa.lv[l].rows, nimg), dim3(256), 0, c->stream, pa, l, c->pyr, c->der);
+    VO_HIP(c, hipGetLastError());
+    return VO_OK;
+}
+
+int launch_match_klt(vo_ctx* c)
+{
+    LkArgs a;
+    a.pa = make_pyr_args(c);
+    a.win = c->p.lk_win;
+    a.max_count = std::min(std::max(c->p.lk_max_count, 0), 100);
+    a.max_features = c->p.max_features;
+    a.min_eig = (float)c->p.lk_min_eig;
+    double eps = std::min(std::max(c->p.lk_epsilon, 0.), 10.);
+    a.eps2 = eps * eps;
+    int nmax = 0;
+    for (int b = 0; b < c->n; b++) nmax = std::max(nmax, c->h_nfeat[b]);
+    if (nmax > 0) {
+        dim3 g((nmax + 3) / 4, c->n), blk(256);
+        const int npl = (a.win * a.win + 63) / 64;
+        if (npl <= 4) hipLaunchKernelGGL((lk_kernel<4>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
+        else if (npl <= 7) hipLaunchKernelGGL((lk_kernel<7>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
+        else hipLaunchKernelGGL((lk_kernel<16>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
+    }
+    hipLaunchKernelGGL(filter_kernel, dim3(c->n), dim3(256), 0, c->stream, c->feat, c->n_feat, c->p.max_features, (float)c->W, (float)c->H,
+                       c->p.loop_threshold, c->legs, c->leg_status, c->m1, c->m2, c->n_match);
+    VO_HIP(c, hipGetLastError());
+    return VO_OK;
+}

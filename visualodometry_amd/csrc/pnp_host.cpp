@@ -1,0 +1,677 @@
+// Host-side minimal solvers and RANSAC bookkeeping (see pnp_host.h).  f64, compiled without FP contraction.
+#include "pnp_host.h"
+#include "small_linalg.h"
+#include <string.h>
+#include <thread>
+#include <atomic>
+#include <functional>
+
+namespace pnp_host {
+
+// ------------------------------------------------------------------ sampling
+void draw_subset(Rng& rng, int count, int model_points, int* idx)
+{
+    int filled = 0;
+    while (filled < model_points) {
+        const int cand = rng.uniform(0, count);
+        bool seen = false;
+        for (int j = 0; j < filled && !seen; j++) seen = idx[j] == cand;
+        if (!seen) idx[filled++] = cand;
+    }
+}
+
+int update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = std::min(std::max(p, 0.), 1.);
+    ep = std::min(std::max(ep, 0.), 1.);
+    double num = std::max(1. - p, DBL_MIN);
+    double denom = 1. - std::pow(1. - ep, model_points);
+    if (denom < DBL_MIN) return 0;
+    num = std::log(num);
+    denom = std::log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)lrint(num / denom);
+}
+
+// ------------------------------------------------------------------ rotations
+void rodrigues_to_matrix(const double r[3], double R[9], double* J)
+{
+    double kx = r[0], ky = r[1], kz = r[2];
+    const double theta = std::sqrt(kx * kx + ky * ky + kz * kz);
+    if (theta < DBL_EPSILON) {
+        for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1 : 0;
+        if (J) { memset(J, 0, 27 * sizeof(double)); J[5] = J[15] = J[19] = -1; J[7] = J[11] = J[21] = 1; }
+        return;
+    }
+    const double c = std::cos(theta), s = std::sin(theta), c1 = 1. - c, itheta = theta ? 1. / theta : 0.;
+    kx *= itheta; ky *= itheta; kz *= itheta;
+    const double kkt[9] = {kx * kx, kx * ky, kx * kz, kx * ky, ky * ky, ky * kz, kx * kz, ky * kz, kz * kz};
+    const double kcross[9] = {0, -kz, ky, kz, 0, -kx, -ky, kx, 0};
+    const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < 9; k++) R[k] = c * eye[k] + c1 * kkt[k] + s * kcross[k];
+    if (!J) return;
+    const double dkkt[27] = {kx + kx, ky, kz, ky, 0, 0, kz, 0, 0,
+                             0, kx, 0, kx, ky + ky, kz, 0, kz, 0,
+                             0, 0, kx, 0, 0, ky, kx, ky, kz + kz};
+    const double dkcross[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0,
+                                0, 0, 1, 0, 0, 0, -1, 0, 0,
+                                0, -1, 0, 1, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; i++) {
+        const double ki = i == 0 ? kx : i == 1 ? ky : kz;
+        const double a0 = -s * ki, a1 = (s - 2 * c1 * itheta) * ki, a2 = c1 * itheta;
+        const double a3 = (c - s * itheta) * ki, a4 = s * itheta;
+        for (int k = 0; k < 9; k++)
+            J[i * 9 + k] = a0 * eye[k] + a1 * kkt[k] + a2 * dkkt[i * 9 + k] + a3 * kcross[k] + a4 * dkcross[i * 9 + k];
+    }
+}
+
+void rodrigues_from_matrix(const double Rin[9], double r[3])
+{
+    sla::SvdWorkspace ws;
+    double W[3], U[9], V[9], R[9];
+    sla::svd(Rin, 3, 3, W, U, V, ws);
+    sla::uvt3(U, V, R); // nearest rotation first
+    double x = R[7] - R[5], y = R[2] - R[6], z = R[3] - R[1];
+    const double s = std::sqrt((x * x + y * y + z * z) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double theta = std::acos(c);
+    if (s < 1e-5) {
+        if (c > 0) x = y = z = 0;
+        else {
+            double t = (R[0] + 1) * 0.5; x = std::sqrt(std::max(t, 0.));
+            t = (R[4] + 1) * 0.5; y = std::sqrt(std::max(t, 0.)) * (R[1] < 0 ? -1. : 1.);
+            t = (R[8] + 1) * 0.5; z = std::sqrt(std::max(t, 0.)) * (R[2] < 0 ? -1. : 1.);
+            if (std::abs(x) < std::abs(y) && std::abs(x) < std::abs(z) && (R[5] > 0) != (y * z > 0)) z = -z;
+            theta /= std::sqrt(x * x + y * y + z * z);
+            x *= theta; y *= theta; z *= theta;
+        }
+    } else {
+        double vth = 1 / (2 * s);
+        vth *= theta;
+        x *= vth; y *= vth; z *= vth;
+    }
+    r[0] = x; r[1] = y; r[2] = z;
+}
+
+bool inv4x4(const double* A, double* Ainv) { return sla::inv_lu(A, 4, Ainv); }
+
+// ------------------------------------------------------------------ EPnP (Lepetit, Moreno-Noguer, Fua)
+namespace {
+
+inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline double sqdist3(const double* a, const double* b)
+{ return (a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) + (a[2] - b[2]) * (a[2] - b[2]); }
+
+struct EpnpProblem {
+    double fu, fv, uc, vc;
+    int n;
+    std::vector<double> world, pix, alpha, cam; // 3n, 2n, 4n, 3n
+    double cw[4][3], cc[4][3];                  // control points, world and camera frame
+    sla::SvdWorkspace ws;
+};
+
+void pick_control_points(EpnpProblem& e)
+{
+    const int n = e.n;
+    e.cw[0][0] = e.cw[0][1] = e.cw[0][2] = 0;
+    for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) e.cw[0][j] += e.world[3 * i + j];
+    for (int j = 0; j < 3; j++) e.cw[0][j] /= n;
+    std::vector<double> centred((size_t)n * 3);
+    for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) centred[3 * i + j] = e.world[3 * i + j] - e.cw[0][j];
+    double cov[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {
+        double s = 0;
+        for (int i = 0; i < n; i++) s += centred[3 * i + r] * centred[3 * i + c];
+        cov[r * 3 + c] = s;
+    }
+    double ev[3], U[9], V[9];
+    sla::svd(cov, 3, 3, ev, U, V, e.ws);
+    for (int i = 1; i < 4; i++) {
+        const double k = std::sqrt(ev[i - 1] / n);
+        for (int j = 0; j < 3; j++) e.cw[i][j] = e.cw[0][j] + k * U[j * 3 + (i - 1)];
+    }
+}
+
+void barycentric_coordinates(EpnpProblem& e)
+{
+    double basis[9], inv[9];
+    for (int i = 0; i < 3; i++) for (int j = 1; j < 4; j++) basis[3 * i + j - 1] = e.cw[j][i] - e.cw[0][i];
+    sla::inv3(basis, inv, e.ws);
+    for (int i = 0; i < e.n; i++) {
+        const double* p = &e.world[3 * i]; double* a = &e.alpha[4 * i];
+        for (int j = 0; j < 3; j++)
+            a[1 + j] = inv[3 * j] * (p[0] - e.cw[0][0]) + inv[3 * j + 1] * (p[1] - e.cw[0][1]) + inv[3 * j + 2] * (p[2] - e.cw[0][2]);
+        a[0] = 1.0f - a[1] - a[2] - a[3];
+    }
+}
+
+void build_L(const double* vt, double* L) // 6 x 10 from the four smallest right singular vectors (rows 11..8 of vt)
+{
+    const double* v[4] = {vt + 12 * 11, vt + 12 * 10, vt + 12 * 9, vt + 12 * 8};
+    double dv[4][6][3];
+    for (int i = 0; i < 4; i++) {
+        int a = 0, b = 1;
+        for (int j = 0; j < 6; j++) {
+            for (int k = 0; k < 3; k++) dv[i][j][k] = v[i][3 * a + k] - v[i][3 * b + k];
+            if (++b > 3) { a++; b = a + 1; }
+        }
+    }
+    for (int i = 0; i < 6; i++) {
+        double* row = L + 10 * i;
+        row[0] = dot3(dv[0][i], dv[0][i]);
+        row[1] = 2.0f * dot3(dv[0][i], dv[1][i]);
+        row[2] = dot3(dv[1][i], dv[1][i]);
+        row[3] = 2.0f * dot3(dv[0][i], dv[2][i]);
+        row[4] = 2.0f * dot3(dv[1][i], dv[2][i]);
+        row[5] = dot3(dv[2][i], dv[2][i]);
+        row[6] = 2.0f * dot3(dv[0][i], dv[3][i]);
+        row[7] = 2.0f * dot3(dv[1][i], dv[3][i]);
+        row[8] = 2.0f * dot3(dv[2][i], dv[3][i]);
+        row[9] = dot3(dv[3][i], dv[3][i]);
+    }
+}
+
+// the three closed-form starts for beta; columns of L are [B11 B12 B22 B13 B23 B33 B14 B24 B34 B44]
+void beta_start(EpnpProblem& e, int which, const double* L, const double* rho, double* beta)
+{
+    if (which == 1) { // [B11 B12 B13 B14]
+        double l[24], x[4];
+        for (int i = 0; i < 6; i++) { l[i * 4] = L[i * 10]; l[i * 4 + 1] = L[i * 10 + 1]; l[i * 4 + 2] = L[i * 10 + 3]; l[i * 4 + 3] = L[i * 10 + 6]; }
+        sla::lstsq(l, 6, 4, rho, x, e.ws);
+        if (x[0] < 0) { beta[0] = std::sqrt(-x[0]); beta[1] = -x[1] / beta[0]; beta[2] = -x[2] / beta[0]; beta[3] = -x[3] / beta[0]; }
+        else { beta[0] = std::sqrt(x[0]); beta[1] = x[1] / beta[0]; beta[2] = x[2] / beta[0]; beta[3] = x[3] / beta[0]; }
+    } else if (which == 2) { // [B11 B12 B22]
+        double l[18], x[3];
+        for (int i = 0; i < 6; i++) { l[i * 3] = L[i * 10]; l[i * 3 + 1] = L[i * 10 + 1]; l[i * 3 + 2] = L[i * 10 + 2]; }
+        sla::lstsq(l, 6, 3, rho, x, e.ws);
+        if (x[0] < 0) { beta[0] = std::sqrt(-x[0]); beta[1] = (x[2] < 0) ? std::sqrt(-x[2]) : 0.0; }
+        else { beta[0] = std::sqrt(x[0]); beta[1] = (x[2] > 0) ? std::sqrt(x[2]) : 0.0; }
+        if (x[1] < 0) beta[0] = -beta[0];
+        beta[2] = 0.0; beta[3] = 0.0;
+    } else { // [B11 B12 B22 B13 B23]
+        double l[30], x[5];
+        for (int i = 0; i < 6; i++) for (int k = 0; k < 5; k++) l[i * 5 + k] = L[i * 10 + k];
+        sla::lstsq(l, 6, 5, rho, x, e.ws);
+        if (x[0] < 0) { beta[0] = std::sqrt(-x[0]); beta[1] = (x[2] < 0) ? std::sqrt(-x[2]) : 0.0; }
+        else { beta[0] = std::sqrt(x[0]); beta[1] = (x[2] > 0) ? std::sqrt(x[2]) : 0.0; }
+        if (x[1] < 0) beta[0] = -beta[0];
+        beta[2] = x[3] / beta[0];
+        beta[3] = 0.0;
+    }
+}
+
+// Householder least squares for the 6x4 Gauss-Newton step (column scale taken over rows k..nr-2, as published)
+void householder_solve(double* A, double* b, double* X, int nr, int nc)
+{
+    double A1[8], A2[8];
+    for (int k = 0; k < nc; k++) {
+        double eta = std::abs(A[k * nc + k]);
+        for (int i = k + 1; i < nr; i++) { const double elt = std::abs(A[(i - 1) * nc + k]); if (eta < elt) eta = elt; }
+        if (eta == 0) { A1[k] = A2[k] = 0.0; return; }
+        double sum2 = 0.0;
+        const double inv_eta = 1. / eta;
+        for (int i = k; i < nr; i++) { A[i * nc + k] *= inv_eta; sum2 += A[i * nc + k] * A[i * nc + k]; }
+        double sigma = std::sqrt(sum2);
+        if (A[k * nc + k] < 0) sigma = -sigma;
+        A[k * nc + k] += sigma;
+        A1[k] = sigma * A[k * nc + k];
+        A2[k] = -eta * sigma;
+        for (int j = k + 1; j < nc; j++) {
+            double sum = 0;
+            for (int i = k; i < nr; i++) sum += A[i * nc + k] * A[i * nc + j];
+            const double tau = sum / A1[k];
+            for (int i = k; i < nr; i++) A[i * nc + j] -= tau * A[i * nc + k];
+        }
+    }
+    for (int j = 0; j < nc; j++) {
+        double tau = 0;
+        for (int i = j; i < nr; i++) tau += A[i * nc + j] * b[i];
+        tau /= A1[j];
+        for (int i = j; i < nr; i++) b[i] -= tau * A[i * nc + j];
+    }
+    X[nc - 1] = b[nc - 1] / A2[nc - 1];
+    for (int i = nc - 2; i >= 0; i--) {
+        double sum = 0;
+        for (int j = i + 1; j < nc; j++) sum += A[i * nc + j] * X[j];
+        X[i] = (b[i] - sum) / A2[i];
+    }
+}
+
+void refine_beta(const double* L, const double* rho, double beta[4])
+{
+    for (int it = 0; it < 5; it++) {
+        double A[24], b[6], x[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 6; i++) {
+            const double* l = L + i * 10; double* a = A + i * 4;
+            a[0] = 2 * l[0] * beta[0] + l[1] * beta[1] + l[3] * beta[2] + l[6] * beta[3];
+            a[1] = l[1] * beta[0] + 2 * l[2] * beta[1] + l[4] * beta[2] + l[7] * beta[3];
+            a[2] = l[3] * beta[0] + l[4] * beta[1] + 2 * l[5] * beta[2] + l[8] * beta[3];
+            a[3] = l[6] * beta[0] + l[7] * beta[1] + l[8] * beta[2] + 2 * l[9] * beta[3];
+            b[i] = rho[i] - (l[0] * beta[0] * beta[0] + l[1] * beta[0] * beta[1] + l[2] * beta[1] * beta[1] +
+                             l[3] * beta[0] * beta[2] + l[4] * beta[1] * beta[2] + l[5] * beta[2] * beta[2] +
+                             l[6] * beta[0] * beta[3] + l[7] * beta[1] * beta[3] + l[8] * beta[2] * beta[3] +
+                             l[9] * beta[3] * beta[3]);
+        }
+        householder_solve(A, b, x, 6, 4);
+        for (int i = 0; i < 4; i++) beta[i] += x[i];
+    }
+}
+
+// absolute orientation (Horn / SVD) between camera-frame and world points, then mean reprojection error
+double pose_from_beta(EpnpProblem& e, const double* vt, const double* beta, double R[3][3], double t[3])
+{
+    const int n = e.n;
+    for (int i = 0; i < 4; i++) e.cc[i][0] = e.cc[i][1] = e.cc[i][2] = 0.0;
+    for (int i = 0; i < 4; i++) {
+        const double* v = vt + 12 * (11 - i);
+        for (int j = 0; j < 4; j++) for (int k = 0; k < 3; k++) e.cc[j][k] += beta[i] * v[3 * j + k];
+    }
+    for (int i = 0; i < n; i++) {
+        const double* a = &e.alpha[4 * i]; double* pc = &e.cam[3 * i];
+        for (int j = 0; j < 3; j++) pc[j] = a[0] * e.cc[0][j] + a[1] * e.cc[1][j] + a[2] * e.cc[2][j] + a[3] * e.cc[3][j];
+    }
+    if (e.cam[2] < 0.0) { // points must lie in front of the camera
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 3; j++) e.cc[i][j] = -e.cc[i][j];
+        for (int i = 0; i < 3 * n; i++) e.cam[i] = -e.cam[i];
+    }
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) { pc0[j] += e.cam[3 * i + j]; pw0[j] += e.world[3 * i + j]; }
+    for (int j = 0; j < 3; j++) { pc0[j] /= n; pw0[j] /= n; }
+    double abt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; i++) {
+        const double* pc = &e.cam[3 * i]; const double* pw = &e.world[3 * i];
+        for (int j = 0; j < 3; j++) {
+            abt[3 * j] += (pc[j] - pc0[j]) * (pw[0] - pw0[0]);
+            abt[3 * j + 1] += (pc[j] - pc0[j]) * (pw[1] - pw0[1]);
+            abt[3 * j + 2] += (pc[j] - pc0[j]) * (pw[2] - pw0[2]);
+        }
+    }
+    double d[3], U[9], V[9];
+    sla::svd(abt, 3, 3, d, U, V, e.ws);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+        R[i][j] = U[3 * i] * V[3 * j] + U[3 * i + 1] * V[3 * j + 1] + U[3 * i + 2] * V[3 * j + 2];
+    const double det = R[0][0] * R[1][1] * R[2][2] + R[0][1] * R[1][2] * R[2][0] + R[0][2] * R[1][0] * R[2][1] -
+                       R[0][2] * R[1][1] * R[2][0] - R[0][1] * R[1][0] * R[2][2] - R[0][0] * R[1][2] * R[2][1];
+    if (det < 0) { R[2][0] = -R[2][0]; R[2][1] = -R[2][1]; R[2][2] = -R[2][2]; }
+    t[0] = pc0[0] - dot3(R[0], pw0); t[1] = pc0[1] - dot3(R[1], pw0); t[2] = pc0[2] - dot3(R[2], pw0);
+    double acc = 0.0;
+    for (int i = 0; i < n; i++) {
+        const double* pw = &e.world[3 * i];
+        const double Xc = dot3(R[0], pw) + t[0], Yc = dot3(R[1], pw) + t[1];
+        const double inv_Zc = 1.0 / (dot3(R[2], pw) + t[2]);
+        const double ue = e.uc + e.fu * Xc * inv_Zc, ve = e.vc + e.fv * Yc * inv_Zc;
+        const double u = e.pix[2 * i], v = e.pix[2 * i + 1];
+        acc += std::sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+    }
+    return acc / n;
+}
+
+} // namespace
+
+void epnp(const vo_point3f* obj, const vo_point2f* img, int n, const double K[9], double rvec[3], double tvec[3])
+{
+    EpnpProblem e;
+    e.fu = K[0]; e.fv = K[4]; e.uc = K[2]; e.vc = K[5]; e.n = n;
+    e.world.resize((size_t)3 * n); e.pix.resize((size_t)2 * n); e.alpha.resize((size_t)4 * n); e.cam.resize((size_t)3 * n);
+    const double ifu = 1. / K[0], ifv = 1. / K[4];
+    for (int i = 0; i < n; i++) {
+        e.world[3 * i] = obj[i].x; e.world[3 * i + 1] = obj[i].y; e.world[3 * i + 2] = obj[i].z;
+        // the image points pass through an undistort step that stores normalised coordinates as float
+        const float xn = (float)(((double)img[i].x - K[2]) * ifu), yn = (float)(((double)img[i].y - K[5]) * ifv);
+        e.pix[2 * i] = xn * e.fu + e.uc;
+        e.pix[2 * i + 1] = yn * e.fv + e.vc;
+    }
+    pick_control_points(e);
+    barycentric_coordinates(e);
+    std::vector<double> M((size_t)2 * n * 12);
+    for (int p = 0; p < n; p++) {
+        const double* as = &e.alpha[4 * p];
+        const double u = e.pix[2 * p], v = e.pix[2 * p + 1];
+        double* r1 = &M[(size_t)(2 * p) * 12]; double* r2 = r1 + 12;
+        for (int i = 0; i < 4; i++) {
+            r1[3 * i] = as[i] * e.fu; r1[3 * i + 1] = 0.0; r1[3 * i + 2] = as[i] * (e.uc - u);
+            r2[3 * i] = 0.0; r2[3 * i + 1] = as[i] * e.fv; r2[3 * i + 2] = as[i] * (e.vc - v);
+        }
+    }
+    double mtm[144];
+    for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) {
+        double s = 0;
+        for (int i = 0; i < 2 * n; i++) s += M[(size_t)i * 12 + r] * M[(size_t)i * 12 + c];
+        mtm[r * 12 + c] = s;
+    }
+    double sv[12], U[144], V[144], vt[144];
+    sla::svd(mtm, 12, 12, sv, U, V, e.ws);
+    for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) vt[r * 12 + c] = V[c * 12 + r];
+    double L[60], rho[6];
+    build_L(vt, L);
+    rho[0] = sqdist3(e.cw[0], e.cw[1]); rho[1] = sqdist3(e.cw[0], e.cw[2]); rho[2] = sqdist3(e.cw[0], e.cw[3]);
+    rho[3] = sqdist3(e.cw[1], e.cw[2]); rho[4] = sqdist3(e.cw[1], e.cw[3]); rho[5] = sqdist3(e.cw[2], e.cw[3]);
+    double beta[4][4], rep[4], Rs[4][3][3], ts[4][3];
+    for (int k = 1; k <= 3; k++) {
+        beta_start(e, k, L, rho, beta[k]);
+        refine_beta(L, rho, beta[k]);
+        rep[k] = pose_from_beta(e, vt, beta[k], Rs[k], ts[k]);
+    }
+    int N = 1;
+    if (rep[2] < rep[1]) N = 2;
+    if (rep[3] < rep[N]) N = 3;
+    double R[9];
+    for (int i = 0; i < 3; i++) { tvec[i] = ts[N][i]; for (int j = 0; j < 3; j++) R[i * 3 + j] = Rs[N][i][j]; }
+    rodrigues_from_matrix(R, rvec);
+}
+
+// ------------------------------------------------------------------ iterative PnP: DLT start + Levenberg-Marquardt
+namespace {
+
+struct Projection { double u, v, x, y, zinv; };
+inline Projection project(const double R[9], const double t[3], const double K[9], double X, double Y, double Z)
+{
+    Projection p;
+    double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+    double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+    double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    z = z ? 1. / z : 1;
+    x *= z; y *= z;
+    p.u = x * K[0] + K[2]; p.v = y * K[4] + K[5];
+    p.x = x; p.y = y; p.zinv = z;
+    return p;
+}
+
+} // namespace
+
+int iterative(const double* obj, const double* img, int n, const double K[9], double rvec[3], double tvec[3])
+{
+    const int max_iter = 20;
+    sla::SvdWorkspace ws;
+    std::vector<double> mn((size_t)2 * n);
+    {
+        const double ifx = 1. / K[0], ify = 1. / K[4];
+        for (int i = 0; i < n; i++) { mn[2 * i] = (img[2 * i] - K[2]) * ifx; mn[2 * i + 1] = (img[2 * i + 1] - K[5]) * ify; }
+    }
+    double Mc[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++) for (int j = 0; j < 3; j++) Mc[j] += obj[3 * i + j];
+    for (int j = 0; j < 3; j++) Mc[j] /= n;
+    double MM[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {
+        double s = 0;
+        for (int i = 0; i < n; i++) s += (obj[3 * i + r] - Mc[r]) * (obj[3 * i + c] - Mc[c]);
+        MM[r * 3 + c] = s;
+    }
+    double W[3], U3[9], V3[9];
+    sla::svd(MM, 3, 3, W, U3, V3, ws);
+    if (W[2] / W[1] < 1e-3) return -2;
+    if (n < 6) return -3;
+    double param[6];
+    {
+        std::vector<double> L((size_t)2 * n * 12);
+        for (int i = 0; i < n; i++) {
+            double* l = &L[(size_t)i * 24];
+            const double x = -mn[2 * i], y = -mn[2 * i + 1];
+            const double* M = &obj[3 * i];
+            l[0] = l[16] = M[0]; l[1] = l[17] = M[1]; l[2] = l[18] = M[2]; l[3] = l[19] = 1.;
+            l[4] = l[5] = l[6] = l[7] = 0.; l[12] = l[13] = l[14] = l[15] = 0.;
+            l[8] = x * M[0]; l[9] = x * M[1]; l[10] = x * M[2]; l[11] = x;
+            l[20] = y * M[0]; l[21] = y * M[1]; l[22] = y * M[2]; l[23] = y;
+        }
+        double LL[144];
+        for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) {
+            double s = 0;
+            for (int i = 0; i < 2 * n; i++) s += L[(size_t)i * 12 + r] * L[(size_t)i * 12 + c];
+            LL[r * 12 + c] = s;
+        }
+        double LW[12], LU[144], LV[144];
+        sla::svd(LL, 12, 12, LW, LU, LV, ws);
+        double P[12];
+        for (int k = 0; k < 12; k++) P[k] = LV[k * 12 + 11];
+        double RR[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
+        double tt[3] = {P[3], P[7], P[11]};
+        if (sla::det3(RR) < 0) { for (int k = 0; k < 9; k++) RR[k] = -RR[k]; for (int k = 0; k < 3; k++) tt[k] = -tt[k]; }
+        double sc = 0;
+        for (int k = 0; k < 9; k++) sc += RR[k] * RR[k];
+        sc = std::sqrt(sc);
+        if (!(std::abs(sc) > DBL_EPSILON)) return -4;
+        double w3[3], u3[9], v3[9], R[9];
+        sla::svd(RR, 3, 3, w3, u3, v3, ws);
+        sla::uvt3(u3, v3, R);
+        double nr = 0;
+        for (int k = 0; k < 9; k++) nr += R[k] * R[k];
+        nr = std::sqrt(nr);
+        for (int k = 0; k < 3; k++) param[3 + k] = tt[k] * (nr / sc);
+        rodrigues_from_matrix(R, param);
+    }
+    const int m = 2 * n;
+    std::vector<double> J((size_t)m * 6), err(m);
+    double prev[6], JtJ[36], JtErr[6];
+    double prevErrNorm = DBL_MAX;
+    int lambdaLg10 = -3, iters = 0;
+    auto evaluate = [&](const double* prm, bool want_J) {
+        double R[9], dRdr[27];
+        rodrigues_to_matrix(prm, R, want_J ? dRdr : nullptr);
+        for (int i = 0; i < n; i++) {
+            const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+            const Projection p = project(R, prm + 3, K, X, Y, Z);
+            err[2 * i] = p.u - img[2 * i]; err[2 * i + 1] = p.v - img[2 * i + 1];
+            if (!want_J) continue;
+            double* jx = &J[(size_t)(2 * i) * 6]; double* jy = jx + 6;
+            const double x = p.x, y = p.y, z = p.zinv;
+            const double dxdt[3] = {z, 0, -x * z}, dydt[3] = {0, z, -y * z};
+            for (int j = 0; j < 3; j++) { jx[3 + j] = K[0] * dxdt[j]; jy[3 + j] = K[4] * dydt[j]; }
+            const double dx0dr[3] = {X * dRdr[0] + Y * dRdr[1] + Z * dRdr[2], X * dRdr[9] + Y * dRdr[10] + Z * dRdr[11], X * dRdr[18] + Y * dRdr[19] + Z * dRdr[20]};
+            const double dy0dr[3] = {X * dRdr[3] + Y * dRdr[4] + Z * dRdr[5], X * dRdr[12] + Y * dRdr[13] + Z * dRdr[14], X * dRdr[21] + Y * dRdr[22] + Z * dRdr[23]};
+            const double dz0dr[3] = {X * dRdr[6] + Y * dRdr[7] + Z * dRdr[8], X * dRdr[15] + Y * dRdr[16] + Z * dRdr[17], X * dRdr[24] + Y * dRdr[25] + Z * dRdr[26]};
+            for (int j = 0; j < 3; j++) {
+                const double dxdr = z * (dx0dr[j] - x * dz0dr[j]);
+                const double dydr = z * (dy0dr[j] - y * dz0dr[j]);
+                jx[j] = K[0] * dxdr; jy[j] = K[4] * dydr;
+            }
+        }
+    };
+    auto err_norm = [&]() { double s = 0; for (int i = 0; i < m; i++) s += err[i] * err[i]; return std::sqrt(s); };
+    auto lm_step = [&]() {
+        const double lambda = std::exp(lambdaLg10 * std::log(10.));
+        double A[36], x[6];
+        for (int k = 0; k < 36; k++) A[k] = JtJ[k];
+        for (int r = 0; r < 6; r++) A[r * 6 + r] *= 1. + lambda;
+        sla::lstsq(A, 6, 6, JtErr, x, ws);
+        for (int i = 0; i < 6; i++) param[i] = prev[i] - x[i];
+    };
+    for (;;) {
+        evaluate(param, true);
+        for (int r = 0; r < 6; r++) {
+            for (int c = r; c < 6; c++) {
+                double s = 0;
+                for (int i = 0; i < m; i++) s += J[(size_t)i * 6 + r] * J[(size_t)i * 6 + c];
+                JtJ[r * 6 + c] = JtJ[c * 6 + r] = s;
+            }
+            double s = 0;
+            for (int i = 0; i < m; i++) s += J[(size_t)i * 6 + r] * err[i];
+            JtErr[r] = s;
+        }
+        memcpy(prev, param, sizeof(param));
+        if (iters == 0) prevErrNorm = err_norm();
+        lm_step();
+        bool done = false;
+        for (;;) {
+            evaluate(param, false);
+            const double errNorm = err_norm();
+            if (errNorm > prevErrNorm && ++lambdaLg10 <= 16) { lm_step(); continue; }
+            lambdaLg10 = std::max(lambdaLg10 - 1, -16);
+            double dn = 0, pn = 0;
+            for (int i = 0; i < 6; i++) { dn += (param[i] - prev[i]) * (param[i] - prev[i]); pn += prev[i] * prev[i]; }
+            if (++iters >= max_iter || std::sqrt(dn) / std::sqrt(pn) < FLT_EPSILON) done = true;
+            prevErrNorm = errNorm;
+            break;
+        }
+        if (done) break;
+    }
+    for (int i = 0; i < 3; i++) { rvec[i] = param[i]; tvec[i] = param[3 + i]; }
+    return 1;
+}
+
+// ------------------------------------------------------------------ batched RANSAC over GPU-scored hypotheses
+namespace {
+
+void parallel_for(int count, int threads, const std::function<void(int)>& fn)
+{
+    threads = std::max(1, std::min(threads, count));
+    if (threads == 1) { for (int i = 0; i < count; i++) fn(i); return; }
+    std::atomic<int> next(0);
+    std::vector<std::thread> pool;
+    auto work = [&]() { for (int i = next.fetch_add(1); i < count; i = next.fetch_add(1)) fn(i); };
+    for (int t = 1; t < threads; t++) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+}
+
+struct FrameRansac {
+    int k = 0;                 // correspondences
+    const vo_point3f* obj = nullptr;
+    const vo_point2f* img = nullptr;
+    Rng rng;
+    int niters = 0, iter = 0, max_good = 0;
+    bool active = false, failed = false, direct = false;
+    double best_r[3] = {0, 0, 0}, best_t[3] = {0, 0, 0};
+    std::vector<uint8_t> best_mask;
+    int nh = 0;                // hypotheses in the current round
+    double hr[64][3], ht[64][3];
+    int best_h = -1;           // hypothesis of this round that became the best model
+};
+
+} // namespace
+
+int estimate_motion_batch(vo_ctx* c, double* Rt_out, vo_frame_info* info)
+{
+    const int n = c->n, chunk = c->p.ransac_chunk;
+    const size_t F = c->p.max_features;
+    const int model_points = 5;
+    int threads = c->p.host_threads > 0 ? c->p.host_threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    const double K[9] = {c->P0[0], c->P0[1], c->P0[2], c->P0[4], c->P0[5], c->P0[6], c->P0[8], c->P0[9], c->P0[10]};
+    const float thresh2 = (float)((double)c->p.ransac_reproj * (double)c->p.ransac_reproj);
+
+    // correspondences of every frame to the host (pinned staging)
+    size_t need = 0;
+    std::vector<size_t> off(n);
+    for (int b = 0; b < n; b++) { off[b] = need; need += (size_t)c->h_nobj[b] * (sizeof(vo_point3f) + sizeof(vo_point2f)); need = (need + 15) & ~(size_t)15; }
+    if (need > c->h_stage_bytes) return vo_fail(c, VO_ERR_CAPACITY, "staging buffer too small");
+    for (int b = 0; b < n; b++) {
+        const int k = c->h_nobj[b];
+        if (k == 0) continue;
+        char* dst = (char*)c->h_stage + off[b];
+        VO_HIP(c, hipMemcpyAsync(dst, c->obj + b * F, (size_t)k * sizeof(vo_point3f), hipMemcpyDeviceToHost, c->stream));
+        VO_HIP(c, hipMemcpyAsync(dst + (size_t)k * sizeof(vo_point3f), c->obj_img + b * F, (size_t)k * sizeof(vo_point2f), hipMemcpyDeviceToHost, c->stream));
+    }
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    // own copies: the staging buffer is reused for hypotheses and masks below
+    std::vector<std::vector<vo_point3f>> objs(n);
+    std::vector<std::vector<vo_point2f>> imgs(n);
+    std::vector<FrameRansac> fr(n);
+    int status = VO_OK;
+    for (int b = 0; b < n; b++) {
+        const int k = c->h_nobj[b];
+        const char* src = (const char*)c->h_stage + off[b];
+        objs[b].assign((const vo_point3f*)src, (const vo_point3f*)src + k);
+        imgs[b].assign((const vo_point2f*)(src + (size_t)k * sizeof(vo_point3f)), (const vo_point2f*)(src + (size_t)k * sizeof(vo_point3f)) + k);
+        FrameRansac& f = fr[b];
+        f.k = k; f.obj = objs[b].data(); f.img = imgs[b].data();
+        f.niters = std::max(c->p.ransac_iters, 1);
+        if (k < 5) { f.failed = true; status = VO_ERR_NOT_ENOUGH_POINTS; } // 4-point P3P kernel is not provided
+        else if (k == model_points) f.direct = true;
+        else f.active = true;
+    }
+
+    double* h_hyp = (double*)c->h_stage;                         // [n][chunk][12]
+    int* h_cnt = (int*)((char*)c->h_stage + (size_t)n * chunk * 12 * sizeof(double)); // [n][chunk]
+    for (;;) {
+        bool any = false;
+        for (int b = 0; b < n; b++) any = any || (fr[b].active && fr[b].iter < fr[b].niters);
+        if (!any) break;
+        // minimal solver on the host: the next `chunk` subsets of every frame still iterating
+        parallel_for(n, threads, [&](int b) {
+            FrameRansac& f = fr[b];
+            f.nh = 0; f.best_h = -1;
+            if (!f.active || f.iter >= f.niters) return;
+            f.nh = std::min(chunk, f.niters - f.iter);
+            for (int h = 0; h < f.nh; h++) {
+                int idx[5];
+                draw_subset(f.rng, f.k, model_points, idx);
+                vo_point3f so[5]; vo_point2f si[5];
+                for (int j = 0; j < 5; j++) { so[j] = f.obj[idx[j]]; si[j] = f.img[idx[j]]; }
+                epnp(so, si, 5, K, f.hr[h], f.ht[h]);
+                double R[9];
+                rodrigues_to_matrix(f.hr[h], R, nullptr);
+                double* dst = h_hyp + ((size_t)b * chunk + h) * 12;
+                memcpy(dst, R, sizeof(R)); dst[9] = f.ht[h][0]; dst[10] = f.ht[h][1]; dst[11] = f.ht[h][2];
+            }
+            for (int h = f.nh; h < chunk; h++) memcpy(h_hyp + ((size_t)b * chunk + h) * 12, h_hyp + ((size_t)b * chunk) * 12, 12 * sizeof(double));
+        });
+        // GPU: score every hypothesis of every frame against all of that frame's correspondences
+        VO_HIP(c, hipMemcpyAsync(c->hyp, h_hyp, (size_t)n * chunk * 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        int rc = launch_pnp_score(c, 0, n, chunk, thresh2, true);
+        if (rc) return rc;
+        VO_HIP(c, hipMemcpyAsync(h_cnt, c->hyp_count, (size_t)n * chunk * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        VO_HIP(c, hipStreamSynchronize(c->stream));
+        // replay the sequential accept rule; hypotheses past the shrinking iteration budget are discarded
+        for (int b = 0; b < n; b++) {
+            FrameRansac& f = fr[b];
+            for (int h = 0; h < f.nh; h++) {
+                if (f.iter >= f.niters) break;
+                const int good = h_cnt[(size_t)b * chunk + h];
+                if (good > std::max(f.max_good, model_points - 1)) {
+                    f.max_good = good; f.best_h = h;
+                    memcpy(f.best_r, f.hr[h], sizeof(f.best_r)); memcpy(f.best_t, f.ht[h], sizeof(f.best_t));
+                    f.niters = update_num_iters(c->p.ransac_conf, (double)(f.k - good) / f.k, model_points, f.niters);
+                }
+                f.iter++;
+            }
+        }
+        // inlier mask of each frame's new best model
+        bool fetch = false;
+        for (int b = 0; b < n; b++) {
+            FrameRansac& f = fr[b];
+            if (f.best_h < 0) continue;
+            f.best_mask.resize(f.k);
+            VO_HIP(c, hipMemcpyAsync(f.best_mask.data(), c->hyp_mask + ((size_t)b * chunk + f.best_h) * F, (size_t)f.k, hipMemcpyDeviceToHost, c->stream));
+            fetch = true;
+        }
+        if (fetch) VO_HIP(c, hipStreamSynchronize(c->stream));
+    }
+
+    // final solve on the inliers, Rodrigues, Rt
+    std::vector<vo_frame_info> li(n);
+    parallel_for(n, threads, [&](int b) {
+        FrameRansac& f = fr[b];
+        vo_frame_info& o = li[b];
+        memset(&o, 0, sizeof(o));
+        o.n_features = c->h_nfeat[b]; o.n_matched = c->h_nmatch[b]; o.n_object_points = f.k;
+        double rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0};
+        if (f.direct) {
+            epnp(f.obj, f.img, f.k, K, rvec, tvec);
+            o.ok = 1; o.best_inliers = f.k;
+        } else if (!f.failed && f.max_good > 0) {
+            o.iters_run = f.iter; o.best_inliers = f.max_good;
+            std::vector<double> po, pi;
+            po.reserve((size_t)f.max_good * 3); pi.reserve((size_t)f.max_good * 2);
+            for (int i = 0; i < f.k; i++) if (f.best_mask[i]) {
+                po.push_back(f.obj[i].x); po.push_back(f.obj[i].y); po.push_back(f.obj[i].z);
+                pi.push_back(f.img[i].x); pi.push_back(f.img[i].y);
+            }
+            const int n1 = (int)(pi.size() / 2);
+            const int res = iterative(po.data(), pi.data(), n1, K, rvec, tvec);
+            if (res > 0) { o.ok = 1; o.final_from_refine = 1; }
+            else {
+                memcpy(rvec, f.best_r, sizeof(rvec)); memcpy(tvec, f.best_t, sizeof(tvec));
+                o.ok = (res == -3 && n1 == 5) ? 1 : 0;
+            }
+        } else o.iters_run = f.iter;
+        double R[9];
+        rodrigues_to_matrix(rvec, R, nullptr);
+        double* Rt = Rt_out + (size_t)b * 16;
+        for (int r = 0; r < 3; r++) { for (int cc = 0; cc < 3; cc++) Rt[r * 4 + cc] = R[r * 3 + cc]; Rt[r * 4 + 3] = tvec[r]; }
+        Rt[12] = Rt[13] = Rt[14] = 0; Rt[15] = 1;
+    });
+    if (info) memcpy(info, li.data(), (size_t)n * sizeof(vo_frame_info));
+    if (status != VO_OK) return vo_fail(c, status, "a frame of the batch has fewer than 5 3D-2D correspondences");
+    return VO_OK;
+}
+
+} // namespace pnp_host

@@ -1,0 +1,471 @@
+// Semi-global block matching, three-path variant, for gfx950.  Integer end to end (u8 -> s16), bit-exact.
+// Replaces cv::StereoSGBM(MODE_SGBM_3WAY)::compute + medianBlur(3) + convertTo(CV_32F, 1/16) as used by
+// VOClass::computeDisparity (reference Source/VOClass.cpp:258-296).
+//
+// Data layout (d fastest): cost volumes are [frame][stripe-row][cost column][D] int16.  The image is cut
+// into 4 fixed stripes with a warm-up overlap; each stripe is an independent run of the vertical path, so a
+// "stripe row" is (stripe, source row) and overlap rows exist once per stripe that needs them.
+//
+//  prefilter_kernel : per pixel and image, the two Birchfield-Tomasi channels (clipped x-Sobel, raw) with
+//                     their half-pixel min/max, packed into 8 bytes.
+//  hsum_kernel      : pixel cost of a row tile into LDS (one evaluation per cell), then the 11-wide
+//                     horizontal window sum, clamped at the ends of the cost row.
+//  vpath_kernel     : 16 lanes x (D/16) disparities per cost column, 4 columns per wavefront, marching down
+//                     the stripe: running 11-row vertical window sum -> aggregated cost C, top-down path L_top.
+//                     The minimum over D is a DPP row reduction; d-1 / d+1 neighbours come from DPP row shifts.
+//  hpath_kernel     : 16 lanes per image row, 4 rows per wavefront, serial along x with register prefetch.
+//                     forward: L_lr, stores L_lr + L_top.  backward: L_rl, S = sum of the three paths,
+//                     winner-take-all with OpenCV's tie rule, sub-pixel fit, packed (minS, d16) per pixel.
+//  lrcheck_kernel   : per image row, right-view disparity by an order-independent LDS atomic-min scatter
+//                     (smallest cost, then largest x), then the two-sided consistency test.
+//  median_kernel    : 3x3 median (replicated border) on the s16 map, plus the /16 float map.
+#include "vo_ctx.h"
+#include <string.h>
+#include <algorithm>
+
+namespace {
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int as_int(v2s v) { return __builtin_bit_cast(int, v); }
+__device__ __forceinline__ v2s as_v2s(int v) { return __builtin_bit_cast(v2s, v); }
+__device__ __forceinline__ v2s splat(int s) { v2s r; r.x = (short)s; r.y = (short)s; return r; }
+__device__ __forceinline__ v2s vmin(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
+
+// reductions over the 16 lanes of a DPP row; every lane ends with the result
+#define DPP_STEP(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xF, 0xF, false)
+__device__ __forceinline__ int row_min(int v)
+{
+    v = min(v, DPP_STEP(v, 0xB1)); v = min(v, DPP_STEP(v, 0x4E));
+    v = min(v, DPP_STEP(v, 0x141)); v = min(v, DPP_STEP(v, 0x140));
+    return v;
+}
+__device__ __forceinline__ int row_max(int v)
+{
+    v = max(v, DPP_STEP(v, 0xB1)); v = max(v, DPP_STEP(v, 0x4E));
+    v = max(v, DPP_STEP(v, 0x141)); v = max(v, DPP_STEP(v, 0x140));
+    return v;
+}
+__device__ __forceinline__ int row_add(int v)
+{
+    v += DPP_STEP(v, 0xB1); v += DPP_STEP(v, 0x4E);
+    v += DPP_STEP(v, 0x141); v += DPP_STEP(v, 0x140);
+    return v;
+}
+__device__ __forceinline__ int row_or(int v)
+{
+    v |= DPP_STEP(v, 0xB1); v |= DPP_STEP(v, 0x4E);
+    v |= DPP_STEP(v, 0x141); v |= DPP_STEP(v, 0x140);
+    return v;
+}
+// value of the previous / next lane of the row; `edge` where there is none
+__device__ __forceinline__ int row_from_prev(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x111, 0xF, 0xF, false); }
+__device__ __forceinline__ int row_from_next(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x101, 0xF, 0xF, false); }
+
+// ---------------------------------------------------------------- prefilter
+__device__ __forceinline__ int grad_clip(const uint8_t* __restrict__ img, size_t pitch, int W, int H, int x, int y, int ftzero)
+{
+    if (x <= 0 || x >= W - 1) return ftzero;
+    const uint8_t* r = img + (size_t)y * pitch;
+    const uint8_t* rn = y > 0 ? r - pitch : r;
+    const uint8_t* rs = y < H - 1 ? r + pitch : r;
+    int v = (r[x + 1] - r[x - 1]) * 2 + rn[x + 1] - rn[x - 1] + rs[x + 1] - rs[x - 1];
+    return min(max(v, -ftzero), ftzero) + ftzero;
+}
+__device__ __forceinline__ int raw_val(const uint8_t* __restrict__ img, size_t pitch, int W, int x, int y, int ftzero)
+{
+    if (x <= 0 || x >= W - 1) return ftzero;
+    return img[(size_t)y * pitch + x];
+}
+
+__global__ __launch_bounds__(256) void prefilter_kernel(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+                                                        size_t pitch, size_t fstride, int W, int H, int Wp, int ftzero,
+                                                        uint2* __restrict__ pre)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int b = blockIdx.z >> 1, which = blockIdx.z & 1;
+    if (x >= W) return;
+    const uint8_t* img = (which ? right : left) + (size_t)b * fstride;
+    int g = grad_clip(img, pitch, W, H, x, y, ftzero);
+    int r = raw_val(img, pitch, W, x, y, ftzero);
+    int gl = g, gr = g, rl = r, rr = r;
+    if (x > 0) { gl = (g + grad_clip(img, pitch, W, H, x - 1, y, ftzero)) >> 1; rl = (r + raw_val(img, pitch, W, x - 1, y, ftzero)) >> 1; }
+    if (x < W - 1) { gr = (g + grad_clip(img, pitch, W, H, x + 1, y, ftzero)) >> 1; rr = (r + raw_val(img, pitch, W, x + 1, y, ftzero)) >> 1; }
+    unsigned g0 = min(min(gl, gr), g), g1 = max(max(gl, gr), g);
+    unsigned r0 = min(min(rl, rr), r), r1 = max(max(rl, rr), r);
+    uint2 o;
+    o.x = (unsigned)g | (g0 << 8) | (g1 << 16);
+    o.y = (unsigned)r | (r0 << 8) | (r1 << 16);
+    pre[(((size_t)b * 2 + which) * H + y) * Wp + x] = o;
+}
+
+// ---------------------------------------------------------------- pixel cost + horizontal window
+__device__ __forceinline__ int bt_channel(unsigned l, unsigned r)
+{
+    int u = l & 0xff, u0 = (l >> 8) & 0xff, u1 = (l >> 16) & 0xff;
+    int v = r & 0xff, v0 = (r >> 8) & 0xff, v1 = (r >> 16) & 0xff;
+    int c0 = max(max(0, u - v1), v0 - u);
+    int c1 = max(max(0, v - u1), u0 - v);
+    return min(c0, c1);
+}
+
+constexpr int HS_TX = 32; // cost columns per block
+
+__global__ __launch_bounds__(256) void hsum_kernel(const uint2* __restrict__ pre, int W, int H, int Wp, int D, int width1, int SW2,
+                                                   int16_t* __restrict__ hsum)
+{
+    extern __shared__ uint8_t pix[]; // [(HS_TX + 2*SW2)][D]
+    const int y = blockIdx.y, b = blockIdx.z;
+    const int tile0 = blockIdx.x * HS_TX;
+    const int minX1 = W - width1;
+    const uint2* L = pre + (((size_t)b * 2 + 0) * H + y) * Wp;
+    const uint2* R = pre + (((size_t)b * 2 + 1) * H + y) * Wp;
+    const int ncol = HS_TX + 2 * SW2;
+    for (int i = threadIdx.x; i < ncol * D; i += 256) {
+        int j = i / D, d = i - j * D;
+        int xc = min(max(tile0 - SW2 + j, 0), width1 - 1);
+        int x = xc + minX1;
+        uint2 l = L[x], r = R[x - d];
+        pix[i] = (uint8_t)(bt_channel(l.x, r.x) + (bt_channel(l.y, r.y) >> 2));
+    }
+    __syncthreads();
+    int16_t* out = hsum + (((size_t)b * H + y) * width1) * D;
+    for (int i = threadIdx.x; i < HS_TX * D; i += 256) {
+        int j = i / D, d = i - j * D;
+        int xc = tile0 + j;
+        if (xc >= width1) break;
+        int s = 0;
+        for (int k = 0; k <= 2 * SW2; k++) s += pix[(j + k) * D + d];
+        out[(size_t)xc * D + d] = (int16_t)s;
+    }
+}
+
+// ---------------------------------------------------------------- one path step on a lane's NP packed pairs
+// L[d] = C[d] + min(Lp[d], Lp[d-1]+P1, Lp[d+1]+P1, m+P2) - (m+P2); returns the minimum of L over the row (all D).
+template <int NP>
+__device__ __forceinline__ int path_step(const v2s (&C)[NP], v2s (&Lp)[NP], int m, int P1, int P2, int inf_pk)
+{
+    const v2s p1 = splat(P1), mp2 = splat(m + P2);
+    int prev_last = row_from_prev(as_int(Lp[NP - 1]), inf_pk);
+    int next_first = row_from_next(as_int(Lp[0]), inf_pk);
+    v2s Ln[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        int lo = k == 0 ? prev_last : as_int(Lp[k - 1]);
+        int hi = k == NP - 1 ? next_first : as_int(Lp[k + 1]);
+        v2s dm1 = as_v2s(__builtin_amdgcn_alignbit(as_int(Lp[k]), lo, 16));
+        v2s dp1 = as_v2s(__builtin_amdgcn_alignbit(hi, as_int(Lp[k]), 16));
+        v2s t = vmin(dm1, dp1) + p1;
+        t = vmin(vmin(t, Lp[k]), mp2);
+        Ln[k] = C[k] + (t - mp2);
+    }
+    v2s mm = Ln[0];
+#pragma unroll
+    for (int k = 1; k < NP; k++) mm = vmin(mm, Ln[k]);
+#pragma unroll
+    for (int k = 0; k < NP; k++) Lp[k] = Ln[k];
+    return row_min(min((int)mm.x, (int)mm.y));
+}
+
+template <int NP>
+__device__ __forceinline__ void load_pk(const int16_t* __restrict__ p, v2s (&v)[NP])
+{
+    const int* q = reinterpret_cast<const int*>(p);
+#pragma unroll
+    for (int k = 0; k < NP; k++) v[k] = as_v2s(q[k]);
+}
+template <int NP>
+__device__ __forceinline__ void store_pk(int16_t* __restrict__ p, const v2s (&v)[NP])
+{
+    int* q = reinterpret_cast<int*>(p);
+#pragma unroll
+    for (int k = 0; k < NP; k++) q[k] = as_int(v[k]);
+}
+
+struct StripeInfo { int y0[4], rows[4], off[4]; };
+
+// ---------------------------------------------------------------- vertical window + top-down path
+template <int NP>
+__global__ __launch_bounds__(256) void vpath_kernel(const int16_t* __restrict__ hsum, int H, int width1, int D, int SH2, int srows,
+                                                    StripeInfo si, int P1, int P2, int16_t* __restrict__ cost, int16_t* __restrict__ agg)
+{
+    const int lane16 = threadIdx.x & 15;
+    const int col = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int stripe = blockIdx.y, b = blockIdx.z;
+    const bool active = col < width1;
+    const int xc = active ? col : width1 - 1;
+    const int y0 = si.y0[stripe], rows = si.rows[stripe];
+    if (rows <= 0) return;
+    const size_t doff = (size_t)xc * D + lane16 * (2 * NP);
+    const int16_t* hs = hsum + ((size_t)b * H) * width1 * D + doff;
+    const size_t rstride = (size_t)width1 * D;
+    size_t orow = ((size_t)b * srows + si.off[stripe]) * rstride + doff;
+    const int inf_pk = (32767 - P1) * 0x10001;
+
+    v2s C[NP], Lp[NP], t[NP];
+    // first row of the stripe: window clamped at the stripe top and at the image bottom
+    load_pk<NP>(hs + (size_t)y0 * rstride, t);
+#pragma unroll
+    for (int k = 0; k < NP; k++) C[k] = t[k] * (short)(SH2 + 1);
+    for (int dy = 1; dy <= SH2; dy++) {
+        load_pk<NP>(hs + (size_t)min(y0 + dy, H - 1) * rstride, t);
+#pragma unroll
+        for (int k = 0; k < NP; k++) C[k] += t[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NP; k++) Lp[k] = splat(0);
+    int m = 0;
+    for (int r = 0; r < rows; r++) {
+        const int y = y0 + r;
+        if (r > 0) {
+            v2s a[NP];
+            load_pk<NP>(hs + (size_t)min(y + SH2, H - 1) * rstride, a);
+            load_pk<NP>(hs + (size_t)max(y - SH2 - 1, y0) * rstride, t);
+#pragma unroll
+            for (int k = 0; k < NP; k++) C[k] += a[k] - t[k];
+        }
+        m = path_step<NP>(C, Lp, m, P1, P2, inf_pk);
+        if (active) {
+            store_pk<NP>(cost + orow, C);
+            store_pk<NP>(agg + orow, Lp);
+        }
+        orow += rstride;
+    }
+}
+
+// ---------------------------------------------------------------- horizontal paths
+constexpr int HP_U = 4; // steps per prefetch group
+
+template <int NP, bool BACKWARD>
+__global__ __launch_bounds__(256) void hpath_kernel(const int16_t* __restrict__ cost, int16_t* __restrict__ agg, int width1, int D,
+                                                    int W, int srows, int P1, int P2, int tie_lanes, int32_t* __restrict__ wta)
+{
+    const int lane16 = threadIdx.x & 15;
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int b = blockIdx.y;
+    const bool active = row < srows;
+    const int sr = active ? row : srows - 1;
+    const size_t base = (((size_t)b * srows + sr) * width1) * D + lane16 * (2 * NP);
+    const int16_t* Cp = cost + base;
+    int16_t* Ap = agg + base;
+    const int inf_pk = (32767 - P1) * 0x10001;
+    const int minX1 = W - width1;
+    const int dbase = lane16 * (2 * NP);
+
+    v2s Lp[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) Lp[k] = splat(0);
+    int m = 0;
+
+    v2s cC[HP_U][NP], cA[HP_U][NP], nC[HP_U][NP], nA[HP_U][NP];
+    auto xof = [&](int step) { return BACKWARD ? width1 - 1 - step : step; };
+    auto load_group = [&](int step0, v2s (&gc)[HP_U][NP], v2s (&ga)[HP_U][NP]) {
+#pragma unroll
+        for (int u = 0; u < HP_U; u++) {
+            int x = xof(min(step0 + u, width1 - 1));
+            load_pk<NP>(Cp + (size_t)x * D, gc[u]);
+            load_pk<NP>(Ap + (size_t)x * D, ga[u]);
+        }
+    };
+    load_group(0, cC, cA);
+    for (int s0 = 0; s0 < width1; s0 += HP_U) {
+        if (s0 + HP_U < width1) load_group(s0 + HP_U, nC, nA);
+#pragma unroll
+        for (int u = 0; u < HP_U; u++) {
+            const int step = s0 + u;
+            if (step < width1) { // uniform
+                const int x = xof(step);
+                m = path_step<NP>(cC[u], Lp, m, P1, P2, inf_pk);
+                if (!BACKWARD) {
+                    v2s o[NP];
+#pragma unroll
+                    for (int k = 0; k < NP; k++) o[k] = Lp[k] + cA[u][k];
+                    if (active) store_pk<NP>(Ap + (size_t)x * D, o);
+                } else {
+                    v2s S[NP];
+#pragma unroll
+                    for (int k = 0; k < NP; k++) S[k] = __builtin_elementwise_add_sat(Lp[k], cA[u][k]);
+                    v2s mm = S[0];
+#pragma unroll
+                    for (int k = 1; k < NP; k++) mm = vmin(mm, S[k]);
+                    const int minS = row_min(min((int)mm.x, (int)mm.y));
+                    // ties: first and count
+                    int first = 1 << 20, cnt = 0;
+#pragma unroll
+                    for (int k = NP - 1; k >= 0; k--) {
+                        if ((int)S[k].y == minS) { first = dbase + 2 * k + 1; cnt++; }
+                        if ((int)S[k].x == minS) { first = dbase + 2 * k; cnt++; }
+                    }
+                    int best = row_min(first);
+                    if (tie_lanes > 0) {
+                        int total = row_add(cnt);
+                        if (__any(total > 1)) {
+                            // vectorised-loop rule: per SIMD lane class the last tie, then the smallest of those
+                            int bb = 1 << 20;
+                            for (int c = 0; c < tie_lanes; c++) {
+                                int last = -1;
+#pragma unroll
+                                for (int k = 0; k < NP; k++) {
+                                    int d0 = dbase + 2 * k;
+                                    if ((int)S[k].x == minS && (d0 % tie_lanes) == c) last = max(last, d0);
+                                    if ((int)S[k].y == minS && ((d0 + 1) % tie_lanes) == c) last = max(last, d0 + 1);
+                                }
+                                last = row_max(last);
+                                if (last >= 0) bb = min(bb, last);
+                            }
+                            best = bb;
+                        }
+                    }
+                    // neighbours of the winner for the parabola fit
+                    int nb = 0;
+#pragma unroll
+                    for (int k = 0; k < NP; k++) {
+                        int d0 = dbase + 2 * k;
+                        if (d0 == best - 1) nb |= (int)S[k].x & 0xffff;
+                        if (d0 + 1 == best - 1) nb |= (int)S[k].y & 0xffff;
+                        if (d0 == best + 1) nb |= ((int)S[k].x & 0xffff) << 16;
+                        if (d0 + 1 == best + 1) nb |= ((int)S[k].y & 0xffff) << 16;
+                    }
+                    nb = row_or(nb);
+                    int d16 = best * 16;
+                    if (best > 0 && best < D - 1) {
+                        int sm = (short)(nb & 0xffff), sp = (short)(nb >> 16);
+                        int denom2 = max(sm + sp - 2 * minS, 1);
+                        d16 += ((sm - sp) * 16 + denom2) / (denom2 * 2);
+                    }
+                    if (active && lane16 == 0)
+                        wta[((size_t)b * srows + sr) * W + (x + minX1)] = (int)(((unsigned)minS << 16) | ((unsigned)d16 & 0xffffu));
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < HP_U; u++)
+#pragma unroll
+            for (int k = 0; k < NP; k++) { cC[u][k] = nC[u][k]; cA[u][k] = nA[u][k]; }
+    }
+}
+
+// ---------------------------------------------------------------- right-view disparity + consistency check
+__global__ __launch_bounds__(256) void lrcheck_kernel(const int32_t* __restrict__ wta, int W, int H, int width1, int srows,
+                                                      StripeInfo si, int stripe_sz, int disp12, int16_t* __restrict__ disp_pre)
+{
+    extern __shared__ unsigned key[]; // [W]
+    const int y = blockIdx.x, b = blockIdx.y;
+    const int stripe = min(y / stripe_sz, 3);
+    const int sr = si.off[stripe] + (y - si.y0[stripe]);
+    const int32_t* w = wta + ((size_t)b * srows + sr) * W;
+    const int minX1 = W - width1;
+    for (int x = threadIdx.x; x < W; x += 256) key[x] = 0xffffffffu;
+    __syncthreads();
+    for (int x = minX1 + threadIdx.x; x < W; x += 256) {
+        int v = w[x];
+        int minS = v >> 16, d16 = (short)(v & 0xffff);
+        int bestd = (d16 + 7) >> 4;
+        if (minS != 32767)
+            atomicMin(&key[x - bestd], ((unsigned)(minS + 32768) << 16) | (unsigned)(0xffff - x));
+    }
+    __syncthreads();
+    int16_t* out = disp_pre + ((size_t)b * H + y) * W;
+    for (int x = threadIdx.x; x < W; x += 256) {
+        int res = -16;
+        if (x >= minX1) {
+            int d1 = (short)(w[x] & 0xffff);
+            int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
+            int _x = x - _d, x_ = x - d_;
+            bool bad = true;
+            {
+                unsigned k = key[_x]; // 0 <= _x because _d <= x - minX1 + ... (d < D <= minX1)
+                int d2 = k == 0xffffffffu ? -16 : (0xffff - (int)(k & 0xffff)) - _x;
+                bad = bad && d2 >= 0 && abs(d2 - _d) > disp12;
+            }
+            {
+                bool inr = x_ >= 0;
+                unsigned k = inr ? key[x_] : 0xffffffffu;
+                int d2 = k == 0xffffffffu ? -16 : (0xffff - (int)(k & 0xffff)) - x_;
+                bad = bad && inr && d2 >= 0 && abs(d2 - d_) > disp12;
+            }
+            res = bad ? -16 : d1;
+        }
+        out[x] = (int16_t)res;
+    }
+}
+
+// ---------------------------------------------------------------- 3x3 median
+#define CSWAP(a, b) { int t_ = min(a, b); b = max(a, b); a = t_; }
+__global__ __launch_bounds__(256) void median_kernel(const int16_t* __restrict__ src, int W, int H, int16_t* __restrict__ dst, float* __restrict__ dstf)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    if (x >= W) return;
+    const int16_t* s = src + (size_t)b * H * W;
+    const int x0 = max(x - 1, 0), x2 = min(x + 1, W - 1), y0 = max(y - 1, 0), y2 = min(y + 1, H - 1);
+    int p0 = s[(size_t)y0 * W + x0], p1 = s[(size_t)y0 * W + x], p2 = s[(size_t)y0 * W + x2];
+    int p3 = s[(size_t)y * W + x0], p4 = s[(size_t)y * W + x], p5 = s[(size_t)y * W + x2];
+    int p6 = s[(size_t)y2 * W + x0], p7 = s[(size_t)y2 * W + x], p8 = s[(size_t)y2 * W + x2];
+    CSWAP(p1, p2); CSWAP(p4, p5); CSWAP(p7, p8); CSWAP(p0, p1); CSWAP(p3, p4); CSWAP(p6, p7);
+    CSWAP(p1, p2); CSWAP(p4, p5); CSWAP(p7, p8); CSWAP(p0, p3); CSWAP(p5, p8); CSWAP(p4, p7);
+    CSWAP(p3, p6); CSWAP(p1, p4); CSWAP(p2, p5); CSWAP(p4, p7); CSWAP(p4, p2); CSWAP(p6, p4);
+    CSWAP(p4, p2);
+    size_t o = ((size_t)b * H + y) * W + x;
+    dst[o] = (int16_t)p4;
+    dstf[o] = (float)p4 * (1.0f / 16.0f);
+}
+
+__global__ __launch_bounds__(256) void depth_kernel(float* __restrict__ disp, size_t count, double fxb, double* __restrict__ depth)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    float d = disp[i];
+    if (d == 0.0f || d == -1.0f) { d = 0.1f; disp[i] = d; }
+    depth[i] = fxb / (double)d;
+}
+
+template <int NP>
+int run_sgbm(vo_ctx* c)
+{
+    const int W = c->W, H = c->H, D = c->D, w1 = c->width1, n = c->n, SH2 = c->p.block_size / 2;
+    const int Wp = W;
+    StripeInfo si;
+    for (int s = 0; s < 4; s++) { si.y0[s] = c->stripe_y0[s]; si.rows[s] = c->stripe_rows[s]; si.off[s] = c->stripe_row_off[s]; }
+    hipLaunchKernelGGL(prefilter_kernel, dim3((W + 255) / 256, H, 2 * n), dim3(256), 0, c->stream, c->img[0], c->img[1], c->pitch,
+                       c->fstride, W, H, Wp, c->ftzero, reinterpret_cast<uint2*>(c->pre));
+    size_t lds = (size_t)(HS_TX + 2 * SH2) * D;
+    hipLaunchKernelGGL(hsum_kernel, dim3((w1 + HS_TX - 1) / HS_TX, H, n), dim3(256), lds, c->stream,
+                       reinterpret_cast<const uint2*>(c->pre), W, H, Wp, D, w1, SH2, c->hsum);
+    hipLaunchKernelGGL((vpath_kernel<NP>), dim3((w1 + 15) / 16, 4, n), dim3(256), 0, c->stream, c->hsum, H, w1, D, SH2, c->srows, si,
+                       c->P1, c->P2, c->cost, c->agg);
+    hipLaunchKernelGGL((hpath_kernel<NP, false>), dim3((c->srows + 15) / 16, n), dim3(256), 0, c->stream, c->cost, c->agg, w1, D, W,
+                       c->srows, c->P1, c->P2, c->p.wta_simd_lanes, c->wta);
+    hipLaunchKernelGGL((hpath_kernel<NP, true>), dim3((c->srows + 15) / 16, n), dim3(256), 0, c->stream, c->cost, c->agg, w1, D, W,
+                       c->srows, c->P1, c->P2, c->p.wta_simd_lanes, c->wta);
+    hipLaunchKernelGGL(lrcheck_kernel, dim3(H, n), dim3(256), (size_t)W * 4, c->stream, c->wta, W, H, w1, c->srows, si, c->stripe_sz,
+                       c->disp12, c->disp_pre);
+    hipLaunchKernelGGL(median_kernel, dim3((W + 255) / 256, H, n), dim3(256), 0, c->stream, c->disp_pre, W, H, c->disp16, c->disp32);
+    VO_HIP(c, hipGetLastError());
+    return VO_OK;
+}
+
+} // namespace
+
+int launch_sgbm(vo_ctx* c)
+{
+    switch (c->D / 32) {
+    case 1: return run_sgbm<1>(c);
+    case 2: return run_sgbm<2>(c);
+    case 3: return run_sgbm<3>(c);
+    case 4: return run_sgbm<4>(c);
+    case 5: return run_sgbm<5>(c);
+    case 6: return run_sgbm<6>(c);
+    case 7: return run_sgbm<7>(c);
+    case 8: return run_sgbm<8>(c);
+    }
+    return vo_fail(c, VO_ERR_BAD_PARAM, "num_disparities must be a multiple of 32 in [32, 256]");
+}
+
+int launch_depth_map(vo_ctx* c)
+{
+    const size_t count = (size_t)c->n * c->W * c->H;
+    const double fx = c->P0[0], baseline = c->P1m[3] / (-1 * fx);
+    hipLaunchKernelGGL(depth_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, c->disp32, count, fx * baseline, c->depth);
+    VO_HIP(c, hipGetLastError());
+    return VO_OK;
+}

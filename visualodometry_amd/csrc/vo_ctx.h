@@ -1,0 +1,112 @@
+// Internal context of the gfx950 stereo front-end: device buffers, derived sizes, launch prototypes.
+#ifndef VO_CTX_H
+#define VO_CTX_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "../../include/vo_abi.h"
+
+#define VO_MAX_LEVELS 8
+
+struct PyrLevel {
+    int w, h;          // level size
+    int pitch;         // bordered row pitch in pixels (w + 2*border, rounded up to 16)
+    int rows;          // h + 2*border
+    size_t img_off;    // byte offset of the bordered u8 level inside one image's pyramid block
+    size_t der_off;    // element offset (int16 pairs counted as 2) inside one image's derivative block
+};
+
+struct vo_ctx {
+    vo_params p;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // derived
+    int W = 0, H = 0, D = 0, width1 = 0;
+    int stripe_sz = 0, overlap = 0;
+    int stripe_y0[4], stripe_rows[4], stripe_row_off[5]; // source row range and offset into the stripe-row volume
+    int srows = 0;                                       // rows of the cost volume per frame (sum of stripe rows)
+    int ftzero = 15, P1 = 0, P2 = 0, disp12 = 1;
+    int nlevels = 0;   // maxLevel actually built (levels 0..nlevels)
+    int border = 0;    // = lk_win
+    PyrLevel lv[VO_MAX_LEVELS];
+    size_t pyr_bytes = 0;   // bytes of one image's bordered pyramid
+    size_t der_elems = 0;   // int16 elements of one image's derivative pyramid
+
+    int n = 0; // frames in the current batch
+    double P0[12], P1m[12];
+    bool have_calib = false;
+
+    // images: [4] = LT1, RT1, LT2, RT2
+    const uint8_t* img[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t pitch = 0, fstride = 0;
+    uint8_t* img_own = nullptr; size_t own_pitch = 0, own_fstride = 0;
+
+    // ---- SGBM ----
+    uint8_t* pre = nullptr;      // prefiltered rows: [n][2 images][H][Wp] x 8 bytes (g,g0,g1,r,r0,r1,0,0)
+    int16_t* hsum = nullptr;     // [n][H][width1][D]
+    int16_t* cost = nullptr;     // [n][srows][width1][D]
+    int16_t* agg = nullptr;      // [n][srows][width1][D]  L_top, then L_top + L_lr
+    int32_t* wta = nullptr;      // [n][srows][W] packed (minS << 16) | (d16 & 0xffff)
+    int16_t* disp_pre = nullptr; // [n][H][W]
+    int16_t* disp16 = nullptr;   // [n][H][W]
+    float* disp32 = nullptr;     // [n][H][W]
+    double* depth = nullptr;     // [n][H][W]
+    bool have_disp = false, have_depth = false;
+
+    // ---- FAST ----
+    uint8_t* score = nullptr;    // [n][H][W]
+    int* row_count = nullptr;    // [n][H]
+    int* row_off = nullptr;      // [n][H]
+    int* n_feat = nullptr;       // [n]  (device)
+    vo_point2f* feat = nullptr;  // [n][max_features]
+    std::vector<int> h_nfeat;    // host copy
+    bool have_features = false;
+
+    // ---- LK ----
+    uint8_t* pyr = nullptr;      // [n][4 images][pyr_bytes]
+    int16_t* der = nullptr;      // [n][4 images][der_elems]
+    vo_point2f* legs = nullptr;  // [n][4][max_features]
+    uint8_t* leg_status = nullptr; // [n][4][max_features]
+    vo_point2f* m1 = nullptr;    // [n][max_features]
+    vo_point2f* m2 = nullptr;
+    int* n_match = nullptr;      // [n]
+    std::vector<int> h_nmatch;
+    bool have_pyr = false, have_matches = false;
+
+    // ---- PnP ----
+    vo_point3f* obj = nullptr;   // [n][max_features]
+    vo_point2f* obj_img = nullptr;
+    int* n_obj = nullptr;
+    std::vector<int> h_nobj;
+    double* hyp = nullptr;       // [n][chunk][12]
+    int* hyp_count = nullptr;    // [n][chunk]
+    uint8_t* hyp_mask = nullptr; // [n][chunk][max_features]
+    bool have_obj = false;
+
+    // pinned host staging
+    void* h_stage = nullptr; size_t h_stage_bytes = 0;
+};
+
+int vo_fail(vo_ctx* c, int code, const char* fmt, ...);
+
+#define VO_HIP(c, call)                                                                           \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) return vo_fail((c), VO_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+// ---- launchers (each enqueues on c->stream, returns a vo_status) ----
+int launch_fast(vo_ctx* c);
+int launch_sgbm(vo_ctx* c);
+int launch_depth_map(vo_ctx* c);
+int launch_pyramids(vo_ctx* c);
+int launch_match_klt(vo_ctx* c);
+int launch_triangulate(vo_ctx* c);
+int launch_pnp_score(vo_ctx* c, int b0, int nb, int H, float thresh2, bool want_masks);
+
+#endif

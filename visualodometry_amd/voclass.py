@@ -1,0 +1,85 @@
+"""Python mirror of the reference's `VOClass` (Include/VOClass.h:62-123) on top of the C ABI.
+
+Same method names, argument meaning and side effects as the reference's hot-path methods, on numpy arrays
+instead of cv::Mat / std::vector<cv::Point2f>:
+
+    vo = VOClass(width, height); vo.setProjectionMatrices(P0, P1)
+    vo.imgLT1, vo.imgRT1, vo.imgLT2, vo.imgRT2 = ...            (public members, Include/VOClass.h:65-66)
+    disp  = vo.computeDisparity(vo.imgLT1, vo.imgRT1)            (Source/VOClass.cpp:231)
+    depth = vo.computeDepthMap(disp)                             (Source/VOClass.cpp:312; patches disp in place)
+    f1    = vo.getFeaturesFAST(vo.imgLT1)                        (Source/VOClassFeatures.cpp:7)
+    f1, f2 = vo.matchFeatureKLT(f1)                              (Source/VOClassFeatures.cpp:54; f1 is replaced)
+    t     = vo.estimateMotion(f1, f2, depth)                     (Source/VOClass.cpp:370; updates vo.poseRt)
+
+The C++ form of the same class is include/VOClass.h.
+"""
+import numpy as np
+from . import abi
+
+
+class VOClass:
+    def __init__(self, width=1241, height=376, device=0, **params):
+        self.frameW, self.frameH = int(width), int(height)
+        self.params = abi.default_params(width, height, **params)
+        self.ctx = abi.Context(self.params, device)
+        self.imgLT1 = self.imgRT1 = self.imgLT2 = self.imgRT2 = None
+        self.poseRt = np.eye(4, dtype=np.float64)
+        self.projectionCL = np.zeros((3, 4))
+        self.projectionCR = np.zeros((3, 4))
+        self._images_key = None
+        self._disp_key = None
+
+    # state that getProjectionMatrices (Source/VOClass.cpp:102) fills from calib.txt
+    def setProjectionMatrices(self, P0, P1):
+        self.projectionCL = np.array(P0, dtype=np.float64).reshape(3, 4)
+        self.projectionCR = np.array(P1, dtype=np.float64).reshape(3, 4)
+        self.ctx.set_calib(self.projectionCL, self.projectionCR)
+
+    def _sync_images(self, lt1=None, rt1=None):
+        lt1 = self.imgLT1 if lt1 is None else lt1
+        rt1 = self.imgRT1 if rt1 is None else rt1
+        lt2 = self.imgLT2 if self.imgLT2 is not None else lt1
+        rt2 = self.imgRT2 if self.imgRT2 is not None else rt1
+        key = tuple(id(a) for a in (lt1, rt1, lt2, rt2))
+        if key != self._images_key:
+            self.ctx.set_images(lt1, rt1, lt2, rt2)
+            self._images_key = key
+            self._disp_key = None
+
+    def computeDisparity(self, leftImg, rightImg):
+        self._sync_images(leftImg, rightImg)
+        self.ctx.compute_disparity()
+        self._disp_key = self._images_key
+        return self.ctx.disparity32(0)
+
+    def computeDepthMap(self, disparityMap):
+        if self._disp_key is None:
+            raise abi.VoError(-5, "computeDisparity has not run on the current images")
+        self.ctx.compute_depth_map()
+        # the reference patches the caller's map in place (shared cv::Mat header)
+        disparityMap[(disparityMap == 0.0) | (disparityMap == -1.0)] = np.float32(0.1)
+        return self.ctx.depth(0)
+
+    def getFeaturesFAST(self, img):
+        self._sync_images(img, None)
+        self.ctx.detect_fast()
+        return self.ctx.features(0)
+
+    def matchFeatureKLT(self, featurePointsLT1):
+        """Returns (featurePointsLT1 after the in/out overwrite, featurePointsLT2)."""
+        self._sync_images()
+        self.ctx.set_features(featurePointsLT1, 0)
+        self.ctx.match_klt()
+        return self.ctx.matches(0)
+
+    def estimateMotion(self, featurePointsT1, featurePointsT2, depthMap=None):
+        assert len(featurePointsT1) == len(featurePointsT2)
+        self.ctx.set_matches(featurePointsT1, featurePointsT2, 0)
+        self.ctx.triangulate()
+        Rt, info = self.ctx.estimate_motion()
+        self.lastInfo = info[0]
+        self.poseRt = abi.integrate_pose(self.poseRt, Rt[0])
+        return self.poseRt[:3, 3].copy().reshape(3, 1)
+
+    def close(self):
+        self.ctx.close()
