@@ -177,6 +177,30 @@ int vo_read_tap(vo_ctx* ctx, int tap, int b, int arg0, int arg1, void* out, size
 /* size in pixels of pyramid level `level`, and the number of levels built (maxLevel) */
 int vo_pyramid_info(vo_ctx* ctx, int level, int* w, int* h, int* max_level);
 
+/* Optional per-stage timing (HIP events on the context's stream around each kernel group; host wall
+ * clock for the host-side PnP part and the whole step).  ms: VO_NUM_STAGES accumulated milliseconds,
+ * calls: how many times each stage ran since the last reset.  No counterpart in the reference. */
+#define VO_NUM_STAGES 16
+typedef enum {
+    VO_ST_PREFILTER = 0, VO_ST_HSUM = 1, VO_ST_VPATH = 2, VO_ST_HPATH_FWD = 3, VO_ST_HPATH_BWD = 4, VO_ST_LRCHECK = 5,
+    VO_ST_MEDIAN = 6, VO_ST_FAST = 7, VO_ST_PYRAMID = 8, VO_ST_LK = 9, VO_ST_FILTER = 10, VO_ST_TRIANGULATE = 11,
+    VO_ST_PNP_SCORE = 12, VO_ST_PNP_HOST = 13, VO_ST_STEP_WALL = 14
+} vo_stage;
+int vo_set_timing(vo_ctx* ctx, int enable);
+int vo_get_timing(vo_ctx* ctx, double* ms, long long* calls, int reset);
+const char* vo_stage_name(int stage);
+
+/* Host-side solvers of estimateMotion, callable without a GPU (used by vo_estimate_motion internally).
+ * vo_host_epnp: solvePnP(SOLVEPNP_EPNP) on n >= 4 float correspondences; K row-major 3x3.
+ * vo_host_pnp_iterative: solvePnP(SOLVEPNP_ITERATIVE) without a guess on f64 correspondences; returns 1,
+ *   or -2 planar object (unsupported), -3 fewer than 6 points, -4 degenerate.
+ * vo_host_rng_subsets: the first nsubsets 5-index subsets cv::RNG((uint64)-1) yields for `count` points.
+ * vo_host_rodrigues: rotation vector -> 3x3 matrix. */
+int vo_host_epnp(const vo_point3f* obj, const vo_point2f* img, int n, const double K[9], double rvec[3], double tvec[3]);
+int vo_host_pnp_iterative(const double* obj, const double* img, int n, const double K[9], double rvec[3], double tvec[3]);
+int vo_host_rng_subsets(int count, int nsubsets, int* idx_out /* nsubsets*5 */);
+int vo_host_rodrigues(const double rvec[3], double R[9]);
+
 #ifdef __cplusplus
 }
 #endif

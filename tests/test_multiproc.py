@@ -1,0 +1,77 @@
+"""The N > 1 path on CPU: two processes over gloo.  Sequences are sharded (LPT), every rank produces the relative
+poses of its own sequences, and ONE all_gather of fixed-size padded buffers gives every rank the complete result;
+integrating on the host then yields the same trajectories as a single process."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from visualodometry_amd import sequence
+
+
+def fake_sequence_Rts(seq_id, steps):
+    """Deterministic stand-in for the per-step [R|t] a GPU would produce (the collective does not care)."""
+    rng = np.random.RandomState(100 + seq_id)
+    out = np.zeros((steps, 16))
+    for k in range(steps):
+        a = rng.normal(0, 0.02)
+        Rt = np.eye(4)
+        Rt[0, 0] = Rt[2, 2] = np.cos(a); Rt[0, 2] = np.sin(a); Rt[2, 0] = -np.sin(a)
+        Rt[:3, 3] = [rng.normal(0, 0.01), 0, -0.8]
+        out[k] = Rt.reshape(16)
+    return out
+
+
+LENGTHS = [9, 4, 12, 3, 2, 7]
+
+
+def worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    owner = sequence.assign_sequences(LENGTHS, world)
+    local = {i: fake_sequence_Rts(i, LENGTHS[i] - 1) for i in owner[rank]}
+    allr = sequence.gather_trajectories(local, len(LENGTHS), max(LENGTHS) - 1)
+    finals = {i: sequence.integrate(allr[i].reshape(-1, 4, 4))[0][-1].tolist() for i in sorted(allr)}
+    q.put((rank, owner, finals))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_sequence_sharding_and_gather_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    owner = res[0][1]
+    assert sorted(i for o in owner for i in o) == list(range(len(LENGTHS)))
+    assert set(owner[0]).isdisjoint(owner[1])
+    # every rank ends up with every sequence, identical to the single-process result
+    want = {i: sequence.integrate(fake_sequence_Rts(i, LENGTHS[i] - 1).reshape(-1, 4, 4))[0][-1].tolist() for i in range(len(LENGTHS))}
+    for rank, _, finals in res:
+        assert finals == want, rank
+
+
+def test_gather_single_process_is_identity():
+    local = {0: fake_sequence_Rts(0, 5), 2: fake_sequence_Rts(2, 3)}
+    out = sequence.gather_trajectories(local, 3, 8)
+    assert sorted(out) == [0, 2] and np.array_equal(out[0], local[0]) and np.array_equal(out[2], local[2])

@@ -23,7 +23,10 @@ EXPORTS = (
     "vo_get_disparity32", "vo_compute_depth_map", "vo_get_depth", "vo_detect_fast", "vo_get_features", "vo_set_features",
     "vo_match_klt", "vo_get_matches", "vo_get_klt_legs", "vo_set_matches", "vo_triangulate", "vo_get_object_points",
     "vo_pnp_score", "vo_estimate_motion", "vo_integrate_pose", "vo_step", "vo_read_tap", "vo_pyramid_info",
+    "vo_set_timing", "vo_get_timing", "vo_stage_name",
+    "vo_host_epnp", "vo_host_pnp_iterative", "vo_host_rng_subsets", "vo_host_rodrigues",
 )
+NUM_STAGES = 16
 
 
 class Point2f(C.Structure):
@@ -70,6 +73,7 @@ def lib():
         L.vo_last_error.restype = C.c_char_p
         L.vo_create_error.restype = C.c_char_p
         L.vo_stream.restype = C.c_void_p
+        L.vo_stage_name.restype = C.c_char_p
         L.vo_destroy.restype = None
         for name in ("vo_set_images", "vo_set_images_device"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
@@ -248,6 +252,22 @@ class Context:
         info = (FrameInfo * n)()
         self._check(self._L.vo_step(self._h, _ptr(Rt), info))
         return Rt, list(info)
+
+    # --- per-stage timing
+    def set_timing(self, enable=True):
+        self._check(self._L.vo_set_timing(self._h, int(bool(enable))))
+
+    def timing(self, reset=False):
+        """{stage name: (accumulated ms, calls)}"""
+        ms = (C.c_double * NUM_STAGES)()
+        calls = (C.c_longlong * NUM_STAGES)()
+        self._check(self._L.vo_get_timing(self._h, ms, calls, int(bool(reset))))
+        out = {}
+        for i in range(NUM_STAGES):
+            name = self._L.vo_stage_name(i).decode()
+            if name:
+                out[name] = (ms[i], calls[i])
+        return out
 
     # --- taps
     def pyramid_info(self, level=0):

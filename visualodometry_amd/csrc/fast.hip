@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) void fast_write_kernel(const uint8_t* __restri
 int launch_fast(vo_ctx* c)
 {
     const int W = c->W, H = c->H, n = c->n;
+    StageTimer st_(c, VO_ST_FAST);
     dim3 g1((W + TILE_W - 1) / TILE_W, (H + TILE_H - 1) / TILE_H, n), b1(TILE_W, 4);
     hipLaunchKernelGGL(fast_score_kernel, g1, b1, 0, c->stream, c->img[0], c->pitch, c->fstride, W, H,
                        c->p.fast_threshold, c->p.fast_nms, c->score);

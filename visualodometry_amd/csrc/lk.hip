@@ -318,6 +318,7 @@ static PyrArgs make_pyr_args(const vo_ctx* c)
 
 int launch_pyramids(vo_ctx* c)
 {
+    StageTimer st_(c, VO_ST_PYRAMID);
     const PyrArgs pa = make_pyr_args(c);
     const int nimg = 4 * c->n;
     hipLaunchKernelGGL(level0_kernel, dim3((pa.lv[0].pitch + 255) / 256, pa.lv[0].rows, nimg), dim3(256), 0, c->stream,
@@ -346,12 +347,14 @@ int launch_match_klt(vo_ctx* c)
     int nmax = 0;
     for (int b = 0; b < c->n; b++) nmax = std::max(nmax, c->h_nfeat[b]);
     if (nmax > 0) {
+        StageTimer st_(c, VO_ST_LK);
         dim3 g((nmax + 3) / 4, c->n), blk(256);
         const int npl = (a.win * a.win + 63) / 64;
         if (npl <= 4) hipLaunchKernelGGL((lk_kernel<4>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
         else if (npl <= 7) hipLaunchKernelGGL((lk_kernel<7>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
         else hipLaunchKernelGGL((lk_kernel<16>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
     }
+    StageTimer st2_(c, VO_ST_FILTER);
     hipLaunchKernelGGL(filter_kernel, dim3(c->n), dim3(256), 0, c->stream, c->feat, c->n_feat, c->p.max_features, (float)c->W, (float)c->H,
                        c->p.loop_threshold, c->legs, c->leg_status, c->m1, c->m2, c->n_match);
     VO_HIP(c, hipGetLastError());

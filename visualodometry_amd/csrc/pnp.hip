@@ -108,6 +108,7 @@ int launch_triangulate(vo_ctx* c)
     a.fxb = a.fx * (c->P1m[3] / (-1 * a.fx));
     a.thresh = (float)c->p.depth_thresh;
     a.W = c->W; a.H = c->H; a.max_features = c->p.max_features; a.use_depth = c->have_depth ? 1 : 0;
+    StageTimer st_(c, VO_ST_TRIANGULATE);
     hipLaunchKernelGGL(triangulate_kernel, dim3(c->n), dim3(256), 0, c->stream, a, c->m1, c->m2, c->n_match, c->disp16, c->depth,
                        c->obj, c->obj_img, c->n_obj);
     VO_HIP(c, hipGetLastError());
@@ -124,6 +125,7 @@ int launch_pnp_score(vo_ctx* c, int b0, int nb, int H, float thresh2, bool want_
     ScoreArgs a;
     a.fx = c->P0[0]; a.fy = c->P0[5]; a.cx = c->P0[2]; a.cy = c->P0[6];
     a.thresh2 = thresh2; a.max_features = c->p.max_features; a.chunk = chunk; a.b0 = b0; a.want_masks = want_masks ? 1 : 0;
+    StageTimer st_(c, VO_ST_PNP_SCORE);
     hipLaunchKernelGGL(score_kernel, dim3((kmax + 255) / 256, H, nb), dim3(256), 0, c->stream, a, c->obj, c->obj_img, c->n_obj, c->hyp,
                        c->hyp_count, c->hyp_mask);
     VO_HIP(c, hipGetLastError());

@@ -5,6 +5,7 @@
 #include <thread>
 #include <atomic>
 #include <functional>
+#include <chrono>
 
 namespace pnp_host {
 
@@ -543,6 +544,7 @@ int estimate_motion_batch(vo_ctx* c, double* Rt_out, vo_frame_info* info)
 {
     const int n = c->n, chunk = c->p.ransac_chunk;
     const size_t F = c->p.max_features;
+    const auto host0 = std::chrono::steady_clock::now();
     const int model_points = 5;
     int threads = c->p.host_threads > 0 ? c->p.host_threads : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     const double K[9] = {c->P0[0], c->P0[1], c->P0[2], c->P0[4], c->P0[5], c->P0[6], c->P0[8], c->P0[9], c->P0[10]};
@@ -670,6 +672,10 @@ int estimate_motion_batch(vo_ctx* c, double* Rt_out, vo_frame_info* info)
         Rt[12] = Rt[13] = Rt[14] = 0; Rt[15] = 1;
     });
     if (info) memcpy(info, li.data(), (size_t)n * sizeof(vo_frame_info));
+    if (c->timing) {
+        c->stage_ms[VO_ST_PNP_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host0).count();
+        c->stage_calls[VO_ST_PNP_HOST]++;
+    }
     if (status != VO_OK) return vo_fail(c, status, "a frame of the batch has fewer than 5 3D-2D correspondences");
     return VO_OK;
 }

@@ -426,20 +426,34 @@ int run_sgbm(vo_ctx* c)
     const int Wp = W;
     StripeInfo si;
     for (int s = 0; s < 4; s++) { si.y0[s] = c->stripe_y0[s]; si.rows[s] = c->stripe_rows[s]; si.off[s] = c->stripe_row_off[s]; }
+    { StageTimer st_(c, VO_ST_PREFILTER);
     hipLaunchKernelGGL(prefilter_kernel, dim3((W + 255) / 256, H, 2 * n), dim3(256), 0, c->stream, c->img[0], c->img[1], c->pitch,
                        c->fstride, W, H, Wp, c->ftzero, reinterpret_cast<uint2*>(c->pre));
+    }
     size_t lds = (size_t)(HS_TX + 2 * SH2) * D;
+    { StageTimer st_(c, VO_ST_HSUM);
     hipLaunchKernelGGL(hsum_kernel, dim3((w1 + HS_TX - 1) / HS_TX, H, n), dim3(256), lds, c->stream,
                        reinterpret_cast<const uint2*>(c->pre), W, H, Wp, D, w1, SH2, c->hsum);
+    }
+    { StageTimer st_(c, VO_ST_VPATH);
     hipLaunchKernelGGL((vpath_kernel<NP>), dim3((w1 + 15) / 16, 4, n), dim3(256), 0, c->stream, c->hsum, H, w1, D, SH2, c->srows, si,
                        c->P1, c->P2, c->cost, c->agg);
+    }
+    { StageTimer st_(c, VO_ST_HPATH_FWD);
     hipLaunchKernelGGL((hpath_kernel<NP, false>), dim3((c->srows + 15) / 16, n), dim3(256), 0, c->stream, c->cost, c->agg, w1, D, W,
                        c->srows, c->P1, c->P2, c->p.wta_simd_lanes, c->wta);
+    }
+    { StageTimer st_(c, VO_ST_HPATH_BWD);
     hipLaunchKernelGGL((hpath_kernel<NP, true>), dim3((c->srows + 15) / 16, n), dim3(256), 0, c->stream, c->cost, c->agg, w1, D, W,
                        c->srows, c->P1, c->P2, c->p.wta_simd_lanes, c->wta);
+    }
+    { StageTimer st_(c, VO_ST_LRCHECK);
     hipLaunchKernelGGL(lrcheck_kernel, dim3(H, n), dim3(256), (size_t)W * 4, c->stream, c->wta, W, H, w1, c->srows, si, c->stripe_sz,
                        c->disp12, c->disp_pre);
+    }
+    { StageTimer st_(c, VO_ST_MEDIAN);
     hipLaunchKernelGGL(median_kernel, dim3((W + 255) / 256, H, n), dim3(256), 0, c->stream, c->disp_pre, W, H, c->disp16, c->disp32);
+    }
     VO_HIP(c, hipGetLastError());
     return VO_OK;
 }

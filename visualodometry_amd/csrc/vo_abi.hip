@@ -6,6 +6,7 @@
 #include <string.h>
 #include <math.h>
 #include <algorithm>
+#include <chrono>
 
 static thread_local std::string g_create_err;
 
@@ -111,6 +112,8 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     if (device < 0 || device >= ndev) return vo_fail(nullptr, VO_ERR_BAD_ARG, "device %d out of range (%d devices)", device, ndev);
     vo_ctx* c = new vo_ctx();
     c->p = *p; c->device = device;
+    memset(c->ev0, 0, sizeof(c->ev0)); memset(c->ev1, 0, sizeof(c->ev1)); memset(c->ev_used, 0, sizeof(c->ev_used));
+    memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(c->stage_calls, 0, sizeof(c->stage_calls));
     if (c->p.ransac_chunk < 1) c->p.ransac_chunk = 8;
     if (c->p.ransac_chunk > 64) c->p.ransac_chunk = 64;
     c->p.fast_threshold = std::min(std::max(c->p.fast_threshold, 0), 255);
@@ -167,6 +170,7 @@ extern "C" void vo_destroy(vo_ctx* c)
                     c->obj, c->obj_img, c->n_obj, c->hyp, c->hyp_count, c->hyp_mask};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (int i = 0; i < VO_NUM_STAGES; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -471,6 +475,7 @@ extern "C" int vo_step(vo_ctx* c, double* Rt_out, vo_frame_info* info)
     if (!c->have_calib) return vo_fail(c, VO_ERR_STATE, "calibration not set");
     if (!Rt_out) return vo_fail(c, VO_ERR_BAD_ARG, "null output");
     VO_HIP(c, hipSetDevice(c->device));
+    const auto wall0 = std::chrono::steady_clock::now();
     int rc;
     // all GPU stages are enqueued back to back; the only host round trips are the feature counts
     if ((rc = launch_sgbm(c))) return rc;
@@ -489,7 +494,79 @@ extern "C" int vo_step(vo_ctx* c, double* Rt_out, vo_frame_info* info)
     memcpy(c->h_nmatch.data(), c->h_stage, c->n * sizeof(int));
     memcpy(c->h_nobj.data(), (char*)c->h_stage + 4096, c->n * sizeof(int));
     c->have_obj = true;
-    return pnp_host::estimate_motion_batch(c, Rt_out, info);
+    rc = pnp_host::estimate_motion_batch(c, Rt_out, info);
+    if (c->timing) {
+        vo_collect_timing(c);
+        c->stage_ms[VO_ST_STEP_WALL] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        c->stage_calls[VO_ST_STEP_WALL]++;
+    }
+    return rc;
+}
+
+static const char* kStageNames[VO_NUM_STAGES] = {"sgbm_prefilter", "sgbm_hsum", "sgbm_vpath", "sgbm_hpath_fwd", "sgbm_hpath_bwd",
+    "sgbm_lrcheck", "sgbm_median", "fast", "pyramid", "lk", "klt_filter", "triangulate", "pnp_score", "pnp_host", "step_wall", ""};
+
+extern "C" const char* vo_stage_name(int s) { return s >= 0 && s < VO_NUM_STAGES ? kStageNames[s] : ""; }
+
+extern "C" int vo_set_timing(vo_ctx* c, int enable)
+{
+    CHECK_CTX(c);
+    VO_HIP(c, hipSetDevice(c->device));
+    if (enable && !c->ev0[0]) {
+        for (int i = 0; i < VO_NUM_STAGES; i++) { VO_HIP(c, hipEventCreate(&c->ev0[i])); VO_HIP(c, hipEventCreate(&c->ev1[i])); }
+    }
+    c->timing = enable != 0;
+    return VO_OK;
+}
+
+void vo_collect_timing(vo_ctx* c)
+{
+    if (!c->timing) return;
+    for (int i = 0; i < VO_NUM_STAGES; i++) {
+        if (!c->ev_used[i]) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev0[i], c->ev1[i]) == hipSuccess) { c->stage_ms[i] += ms; c->stage_calls[i]++; }
+        c->ev_used[i] = false;
+    }
+}
+
+extern "C" int vo_get_timing(vo_ctx* c, double* ms, long long* calls, int reset)
+{
+    CHECK_CTX(c);
+    for (int i = 0; i < VO_NUM_STAGES; i++) {
+        if (ms) ms[i] = c->stage_ms[i];
+        if (calls) calls[i] = c->stage_calls[i];
+        if (reset) { c->stage_ms[i] = 0; c->stage_calls[i] = 0; }
+    }
+    return VO_OK;
+}
+
+extern "C" int vo_host_epnp(const vo_point3f* obj, const vo_point2f* img, int n, const double K[9], double rvec[3], double tvec[3])
+{
+    if (!obj || !img || !K || !rvec || !tvec || n < 4) return VO_ERR_BAD_ARG;
+    pnp_host::epnp(obj, img, n, K, rvec, tvec);
+    return VO_OK;
+}
+
+extern "C" int vo_host_pnp_iterative(const double* obj, const double* img, int n, const double K[9], double rvec[3], double tvec[3])
+{
+    if (!obj || !img || !K || !rvec || !tvec || n < 1) return VO_ERR_BAD_ARG;
+    return pnp_host::iterative(obj, img, n, K, rvec, tvec);
+}
+
+extern "C" int vo_host_rng_subsets(int count, int nsubsets, int* idx_out)
+{
+    if (count < 5 || nsubsets < 0 || !idx_out) return VO_ERR_BAD_ARG;
+    pnp_host::Rng rng;
+    for (int s = 0; s < nsubsets; s++) pnp_host::draw_subset(rng, count, 5, idx_out + (size_t)s * 5);
+    return VO_OK;
+}
+
+extern "C" int vo_host_rodrigues(const double rvec[3], double R[9])
+{
+    if (!rvec || !R) return VO_ERR_BAD_ARG;
+    pnp_host::rodrigues_to_matrix(rvec, R, nullptr);
+    return VO_OK;
 }
 
 extern "C" int vo_pyramid_info(vo_ctx* c, int level, int* w, int* h, int* max_level)

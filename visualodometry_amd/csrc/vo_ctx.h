@@ -10,6 +10,7 @@
 #include "../../include/vo_abi.h"
 
 #define VO_MAX_LEVELS 8
+#define VO_NUM_STAGES 16
 
 struct PyrLevel {
     int w, h;          // level size
@@ -90,7 +91,21 @@ struct vo_ctx {
 
     // pinned host staging
     void* h_stage = nullptr; size_t h_stage_bytes = 0;
+
+    // optional per-stage timing with HIP events on the context's stream
+    bool timing = false;
+    hipEvent_t ev0[VO_NUM_STAGES], ev1[VO_NUM_STAGES];
+    bool ev_used[VO_NUM_STAGES];
+    double stage_ms[VO_NUM_STAGES];
+    long long stage_calls[VO_NUM_STAGES];
 };
+
+struct StageTimer {
+    vo_ctx* c; int id;
+    StageTimer(vo_ctx* c_, int id_) : c(c_), id(id_) { if (c->timing) { (void)hipEventRecord(c->ev0[id], c->stream); } }
+    ~StageTimer() { if (c->timing) { (void)hipEventRecord(c->ev1[id], c->stream); c->ev_used[id] = true; } }
+};
+void vo_collect_timing(vo_ctx* c); // after a stream synchronise: adds the recorded intervals to stage_ms
 
 int vo_fail(vo_ctx* c, int code, const char* fmt, ...);
 

@@ -1,0 +1,87 @@
+"""Sequence driver and sequence-level sharding.
+
+The reference's main loop (Source/main.cpp:30-65) walks frame pairs (t, t+1) of one sequence and integrates
+poseRt = poseRt * Rt^-1 (Source/VOClass.cpp:587).  A pair reads nothing from the previous pair except poseRt,
+so pairs are independent up to an ordered product of 4x4 matrices: run_sequence() pushes B consecutive pairs
+through the GPU per call and does the ordered product on the host with the library's LU inverse, which gives the
+same trajectory as the one-pair-at-a-time loop.
+
+Across GPUs the unit of work is a whole sequence (or a contiguous chunk of one): assign_sequences() is
+longest-processing-time-first; gather_trajectories() is the single collective of a run (RCCL on GPUs, gloo in
+the CPU tests), after all frames are done.
+"""
+import numpy as np
+
+from . import abi
+
+
+def assign_sequences(lengths, world_size):
+    """LPT assignment: returns a list (one entry per rank) of sequence indices; deterministic."""
+    order = sorted(range(len(lengths)), key=lambda i: (-lengths[i], i))
+    load = [0] * world_size
+    owner = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (load[k], k))
+        owner[r].append(i)
+        load[r] += max(lengths[i] - 1, 0)  # a sequence of n frames has n-1 steps
+    return owner
+
+
+def integrate(Rts, pose0=None):
+    """Ordered product pose_k = pose_{k-1} * inv(Rt_k); returns (k+1) x 3 translations starting at pose0's."""
+    pose = np.eye(4) if pose0 is None else np.array(pose0, dtype=np.float64)
+    traj = [pose[:3, 3].copy()]
+    for Rt in Rts:
+        pose = abi.integrate_pose(pose, Rt)
+        traj.append(pose[:3, 3].copy())
+    return np.array(traj), pose
+
+
+def trajectory_rmse(estimated, ground_truth):
+    """VOClass::computeErrorInPoseEstimation (Source/VOClass.cpp:627-649): float accumulator, RMSE of translations."""
+    err = np.float32(0)
+    for e, g in zip(np.asarray(estimated, dtype=np.float64), np.asarray(ground_truth, dtype=np.float64)):
+        err = np.float32(err + ((g[0] - e[0]) ** 2 + (g[1] - e[1]) ** 2 + (g[2] - e[2]) ** 2))
+    return float(np.float32(np.sqrt(np.float32(err / len(estimated)))))
+
+
+def run_sequence(ctx, frames, batch=None):
+    """frames: list of (left, right) u8 images.  Returns (relative Rt per step [n-1,4,4], frame infos)."""
+    n = len(frames)
+    batch = batch or ctx.params.max_batch
+    Rts, infos = [], []
+    for s in range(0, n - 1, batch):
+        e = min(s + batch, n - 1)
+        lt1 = np.stack([frames[i][0] for i in range(s, e)])
+        rt1 = np.stack([frames[i][1] for i in range(s, e)])
+        lt2 = np.stack([frames[i + 1][0] for i in range(s, e)])
+        rt2 = np.stack([frames[i + 1][1] for i in range(s, e)])
+        ctx.set_images(lt1, rt1, lt2, rt2)
+        Rt, info = ctx.step()
+        Rts.extend(Rt)
+        infos.extend(info)
+    return np.array(Rts), infos
+
+
+def gather_trajectories(local, n_sequences, max_steps, group=None):
+    """local: {sequence index: [steps, 16] relative Rt}.  One all_gather of fixed-size padded buffers;
+    returns {sequence index: [steps, 16]} for all sequences on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    buf = torch.zeros((n_sequences, max_steps, 16), dtype=torch.float64)
+    cnt = torch.zeros((n_sequences,), dtype=torch.int64)
+    for i, Rt in local.items():
+        a = np.asarray(Rt, dtype=np.float64).reshape(-1, 16)
+        buf[i, :a.shape[0]] = torch.from_numpy(a)
+        cnt[i] = a.shape[0]
+    if world > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        buf, cnt = buf.to(dev), cnt.to(dev)
+        bufs = [torch.empty_like(buf) for _ in range(world)]
+        cnts = [torch.empty_like(cnt) for _ in range(world)]
+        dist.all_gather(bufs, buf, group=group)
+        dist.all_gather(cnts, cnt, group=group)
+        buf = torch.stack(bufs).sum(0).cpu()   # every sequence is owned by exactly one rank; the others hold zeros
+        cnt = torch.stack(cnts).sum(0).cpu()
+    return {i: buf[i, :int(cnt[i])].numpy().copy() for i in range(n_sequences) if int(cnt[i]) > 0}
