@@ -81,9 +81,11 @@ def cpu_baseline(frames, seq, shape, sample_pairs):
     ob.set_threads(threads)
     p = ob.default_params(shape["width"], shape["height"], num_disparities=shape["num_disparities"], lk_win=shape["lk_win"])
     pose = np.eye(4)
-    npairs = min(sample_pairs, len(frames) - 1)
+    npairs = sample_pairs
+    nd = len(frames) - 1
     t0 = time.perf_counter()
-    for i in range(npairs):
+    for k in range(npairs):
+        i = k % nd
         ob.step(frames[i][0], frames[i][1], frames[i + 1][0], frames[i + 1][1], p, seq.P0, seq.P1, pose)
     dt = time.perf_counter() - t0
     return {"value": npairs / dt, "unit": "stereo frames/s", "cores": threads, "kind": "port",
@@ -99,9 +101,10 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--workload", default="kitti", choices=["kitti", "4k"])
     ap.add_argument("--distinct", type=int, default=4, help="distinct frame pairs rendered (tiled to fill the batch)")
-    ap.add_argument("--cpu-pairs", type=int, default=6)
+    ap.add_argument("--cpu-pairs", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--inflight", type=int, default=2, help="contexts taking turns (overlaps host PnP with GPU work)")
     args = ap.parse_args()
 
     import torch
@@ -137,24 +140,47 @@ def main():
 
     p = abi.default_params(W, H, max_batch=B, num_disparities=D, lk_win=shape["lk_win"], max_features=shape["max_features"],
                            host_threads=args.host_threads)
-    ctx = abi.Context(p, local_rank)
-    ctx.set_calib(seq.P0, seq.P1)
-    ctx.set_images_device(B, [t.data_ptr() for t in (lt1, rt1, lt2, rt2)], W, W * H, keep=(lt1, rt1, lt2, rt2))
+    # `inflight` contexts take turns: while the host part (minimal solvers, refine) of one batch runs, the GPU
+    # part of the next batch is already enqueued on the other context's stream
+    ctxs = []
+    for _ in range(max(1, args.inflight)):
+        c = abi.Context(p, local_rank)
+        c.set_calib(seq.P0, seq.P1)
+        c.set_images_device(B, [t.data_ptr() for t in (lt1, rt1, lt2, rt2)], W, W * H, keep=(lt1, rt1, lt2, rt2))
+        ctxs.append(c)
+    ctx = ctxs[0]
+    nctx = len(ctxs)
 
-    for _ in range(args.warmup):
-        Rt, info = ctx.step()
-    ctx.set_timing(True)
-    ctx.timing(reset=True)
+    def run_steps(k):
+        """k whole batches through the path, pipeline fill and drain included"""
+        out = None
+        for s in range(min(nctx, k)):
+            ctxs[s].step_submit()
+        for s in range(k):
+            c = ctxs[s % nctx]
+            out = c.step_finish()
+            if s + nctx < k:
+                c.step_submit()
+        return out
+
+    if args.warmup > 0:
+        Rt, info = run_steps(args.warmup)
+    for c in ctxs:
+        c.set_timing(True)
+        c.timing(reset=True)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    barrier(); torch.cuda.synchronize(); ctx.synchronize()
+    barrier(); torch.cuda.synchronize()
+    for c in ctxs:
+        c.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        Rt, info = ctx.step()
-    ctx.synchronize(); torch.cuda.synchronize()
+    Rt, info = run_steps(args.steps)
+    for c in ctxs:
+        c.synchronize()
+    torch.cuda.synchronize()
     # the only collective: gather the per-frame relative poses of every rank (result gather, RCCL over xGMI)
     poses = torch.from_numpy(Rt).to(dev)
     if world > 1:
@@ -168,7 +194,11 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    timing = ctx.timing()
+    timing = {}
+    for c in ctxs:
+        for k, v in c.timing().items():
+            a = timing.get(k, (0.0, 0))
+            timing[k] = (a[0] + v[0], a[1] + v[1])
     if rank == 0:
         steps = args.steps
         fps = world * B * steps / dt
@@ -193,7 +223,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s-shape synthetic stereo, %dx%d, %d disparities, %d frame pairs per step per GPU, whole hot path "
                                    "(SGBM-3way + FAST + circular KLT + triangulation + PnP-RANSAC)" % (args.workload, W, H, D, B),
-                       "batch": B, "sharding": "independent sequences, one per GPU; poses all-gathered once (RCCL)",
+                       "batch": B, "batches_in_flight": nctx, "sharding": "independent sequences, one per GPU; poses all-gathered once (RCCL)",
                        "mpix_per_s": fps * W * H / 1e6,
                        "features_per_frame": int(np.mean([i.n_features for i in info])),
                        "matches_per_frame": int(np.mean([i.n_matched for i in info])),

@@ -164,6 +164,12 @@ int vo_integrate_pose(double pose_inout[16], const double Rt[16]);
 /* One iteration of Source/main.cpp:36-60 for n frame pairs, images already set:
  * disparity, FAST, circular KLT, triangulation, PnP.  Same results as the stage calls in sequence. */
 int vo_step(vo_ctx* ctx, double* Rt_out /* n*16 */, vo_frame_info* info /* nullable, n */);
+/* The same step in two halves, so that a caller with two contexts can overlap the host part (minimal
+ * solvers, final refine) of one batch with the GPU part of the next: vo_step_submit enqueues every GPU
+ * stage and returns without waiting; vo_step_finish waits for them and runs the host part.
+ * vo_step(ctx, ...) == vo_step_submit(ctx) followed by vo_step_finish(ctx, ...). */
+int vo_step_submit(vo_ctx* ctx);
+int vo_step_finish(vo_ctx* ctx, double* Rt_out /* n*16 */, vo_frame_info* info /* nullable, n */);
 
 /* Test taps: intermediate buffers of frame b copied to the host. */
 typedef enum {

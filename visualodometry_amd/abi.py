@@ -22,7 +22,7 @@ EXPORTS = (
     "vo_set_calib", "vo_set_images", "vo_set_images_device", "vo_compute_disparity", "vo_get_disparity16",
     "vo_get_disparity32", "vo_compute_depth_map", "vo_get_depth", "vo_detect_fast", "vo_get_features", "vo_set_features",
     "vo_match_klt", "vo_get_matches", "vo_get_klt_legs", "vo_set_matches", "vo_triangulate", "vo_get_object_points",
-    "vo_pnp_score", "vo_estimate_motion", "vo_integrate_pose", "vo_step", "vo_read_tap", "vo_pyramid_info",
+    "vo_pnp_score", "vo_estimate_motion", "vo_integrate_pose", "vo_step", "vo_step_submit", "vo_step_finish", "vo_read_tap", "vo_pyramid_info",
     "vo_set_timing", "vo_get_timing", "vo_stage_name",
     "vo_host_epnp", "vo_host_pnp_iterative", "vo_host_rng_subsets", "vo_host_rodrigues",
 )
@@ -251,6 +251,16 @@ class Context:
         Rt = np.zeros((n, 4, 4), dtype=np.float64)
         info = (FrameInfo * n)()
         self._check(self._L.vo_step(self._h, _ptr(Rt), info))
+        return Rt, list(info)
+
+    def step_submit(self):
+        self._check(self._L.vo_step_submit(self._h))
+
+    def step_finish(self):
+        n = self.n
+        Rt = np.zeros((n, 4, 4), dtype=np.float64)
+        info = (FrameInfo * n)()
+        self._check(self._L.vo_step_finish(self._h, _ptr(Rt), info))
         return Rt, list(info)
 
     # --- per-stage timing

@@ -334,7 +334,7 @@ int launch_pyramids(vo_ctx* c)
     return VO_OK;
 }
 
-int launch_match_klt(vo_ctx* c)
+int launch_match_klt(vo_ctx* c, bool counts_on_host)
 {
     LkArgs a;
     a.pa = make_pyr_args(c);
@@ -344,8 +344,9 @@ int launch_match_klt(vo_ctx* c)
     a.min_eig = (float)c->p.lk_min_eig;
     double eps = std::min(std::max(c->p.lk_epsilon, 0.), 10.);
     a.eps2 = eps * eps;
-    int nmax = 0;
-    for (int b = 0; b < c->n; b++) nmax = std::max(nmax, c->h_nfeat[b]);
+    // without host-side counts the grid covers the capacity; wavefronts past a frame's feature count exit at once
+    int nmax = counts_on_host ? 0 : c->p.max_features;
+    if (counts_on_host) for (int b = 0; b < c->n; b++) nmax = std::max(nmax, c->h_nfeat[b]);
     if (nmax > 0) {
         StageTimer st_(c, VO_ST_LK);
         dim3 g((nmax + 3) / 4, c->n), blk(256);

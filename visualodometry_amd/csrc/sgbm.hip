@@ -100,44 +100,19 @@ __global__ __launch_bounds__(256) void prefilter_kernel(const uint8_t* __restric
 }
 
 // ---------------------------------------------------------------- pixel cost + horizontal window
-__device__ __forceinline__ int bt_channel(unsigned l, unsigned r)
+// Birchfield-Tomasi cost of one channel for two adjacent disparities at once (packed 16-bit lanes).
+// u, u0, u1: the left pixel's value / half-pixel min / max, splatted.  ra, rb: the right pixels for the
+// lower and the upper disparity of the pair, bytes (v, v0, v1, -).
+__device__ __forceinline__ v2s vmax(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ v2s bt_pair(v2s u, v2s u0, v2s u1, unsigned ra, unsigned rb)
 {
-    int u = l & 0xff, u0 = (l >> 8) & 0xff, u1 = (l >> 16) & 0xff;
-    int v = r & 0xff, v0 = (r >> 8) & 0xff, v1 = (r >> 16) & 0xff;
-    int c0 = max(max(0, u - v1), v0 - u);
-    int c1 = max(max(0, v - u1), u0 - v);
-    return min(c0, c1);
-}
-
-constexpr int HS_TX = 32; // cost columns per block
-
-__global__ __launch_bounds__(256) void hsum_kernel(const uint2* __restrict__ pre, int W, int H, int Wp, int D, int width1, int SW2,
-                                                   int16_t* __restrict__ hsum)
-{
-    extern __shared__ uint8_t pix[]; // [(HS_TX + 2*SW2)][D]
-    const int y = blockIdx.y, b = blockIdx.z;
-    const int tile0 = blockIdx.x * HS_TX;
-    const int minX1 = W - width1;
-    const uint2* L = pre + (((size_t)b * 2 + 0) * H + y) * Wp;
-    const uint2* R = pre + (((size_t)b * 2 + 1) * H + y) * Wp;
-    const int ncol = HS_TX + 2 * SW2;
-    for (int i = threadIdx.x; i < ncol * D; i += 256) {
-        int j = i / D, d = i - j * D;
-        int xc = min(max(tile0 - SW2 + j, 0), width1 - 1);
-        int x = xc + minX1;
-        uint2 l = L[x], r = R[x - d];
-        pix[i] = (uint8_t)(bt_channel(l.x, r.x) + (bt_channel(l.y, r.y) >> 2));
-    }
-    __syncthreads();
-    int16_t* out = hsum + (((size_t)b * H + y) * width1) * D;
-    for (int i = threadIdx.x; i < HS_TX * D; i += 256) {
-        int j = i / D, d = i - j * D;
-        int xc = tile0 + j;
-        if (xc >= width1) break;
-        int s = 0;
-        for (int k = 0; k <= 2 * SW2; k++) s += pix[(j + k) * D + d];
-        out[(size_t)xc * D + d] = (int16_t)s;
-    }
+    const v2s v = as_v2s((int)__builtin_amdgcn_perm(rb, ra, 0x0c040c00u));
+    const v2s v0 = as_v2s((int)__builtin_amdgcn_perm(rb, ra, 0x0c050c01u));
+    const v2s v1 = as_v2s((int)__builtin_amdgcn_perm(rb, ra, 0x0c060c02u));
+    const v2s zero = splat(0);
+    const v2s c0 = vmax(vmax(zero, u - v1), v0 - u);
+    const v2s c1 = vmax(vmax(zero, v - u1), u0 - v);
+    return vmin(c0, c1);
 }
 
 // ---------------------------------------------------------------- one path step on a lane's NP packed pairs
@@ -184,50 +159,125 @@ __device__ __forceinline__ void store_pk(int16_t* __restrict__ p, const v2s (&v)
 
 struct StripeInfo { int y0[4], rows[4], off[4]; };
 
-// ---------------------------------------------------------------- vertical window + top-down path
+// ---------------------------------------------------------------- pixel cost + 11x11 window + top-down path, fused
+// Block = 256 threads = 16 lane groups x 16 lanes; a lane group owns 4 adjacent tile columns (64 per block,
+// SW2 of them on each side are halo), a lane 2*NP consecutive disparities of each.  Marching down the stripe:
+//   V(x, d)  = running vertical window sum of the pixel cost (both the entering and the leaving image row are
+//              re-evaluated from the prefiltered rows: no cost ring buffer, no cost volume read back),
+//   C(x, d)  = horizontal window sum of V through LDS (sliding over the group's 4 columns),
+//   L_top    = one path step per column; C and L_top are the only HBM traffic (one write each).
+constexpr int CV_COLS = 64;
+
 template <int NP>
-__global__ __launch_bounds__(256) void vpath_kernel(const int16_t* __restrict__ hsum, int H, int width1, int D, int SH2, int srows,
-                                                    StripeInfo si, int P1, int P2, int16_t* __restrict__ cost, int16_t* __restrict__ agg)
+__global__ __launch_bounds__(256) void cost_vpath_kernel(const uint2* __restrict__ pre, int W, int H, int Wp, int width1, int D, int SW2,
+                                                         int srows, StripeInfo si, int P1, int P2, int16_t* __restrict__ cost,
+                                                         int16_t* __restrict__ agg)
 {
-    const int lane16 = threadIdx.x & 15;
-    const int col = blockIdx.x * 16 + (threadIdx.x >> 4);
+    extern __shared__ int vt[]; // [2][CV_COLS][CS]: V of every tile column, dword (k, lane16) at k*16 + lane16
+    constexpr int CS = 16 * NP + 4;
+    constexpr int NR = 2 * NP + 3;
+    const int lane16 = threadIdx.x & 15, q = threadIdx.x >> 4;
     const int stripe = blockIdx.y, b = blockIdx.z;
-    const bool active = col < width1;
-    const int xc = active ? col : width1 - 1;
     const int y0 = si.y0[stripe], rows = si.rows[stripe];
     if (rows <= 0) return;
-    const size_t doff = (size_t)xc * D + lane16 * (2 * NP);
-    const int16_t* hs = hsum + ((size_t)b * H) * width1 * D + doff;
-    const size_t rstride = (size_t)width1 * D;
-    size_t orow = ((size_t)b * srows + si.off[stripe]) * rstride + doff;
-    const int inf_pk = (32767 - P1) * 0x10001;
+    const int tile_out = CV_COLS - 2 * SW2;
+    const int xc0 = blockIdx.x * tile_out - SW2; // cost column of tile column 0
+    const int minX1 = W - width1;
+    const int cb = q * 4;
+    const int d0 = lane16 * 2 * NP;
+    const uint2* Lb = pre + ((size_t)b * 2 + 0) * H * Wp;
+    const uint2* Rb = pre + ((size_t)b * 2 + 1) * H * Wp;
+    int xl[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) xl[j] = minX1 + min(max(xc0 + cb + j, 0), width1 - 1);
+    // right pixel of (column j, slot s) is r[j - s + 2NP - 1] with r[i] = R[xr0 + i]
+    const int xr0 = minX1 + xc0 + cb - d0 - (2 * NP - 1);
+    int xr[NR];
+#pragma unroll
+    for (int i = 0; i < NR; i++) xr[i] = min(max(xr0 + i, 0), W - 1);
 
-    v2s C[NP], Lp[NP], t[NP];
-    // first row of the stripe: window clamped at the stripe top and at the image bottom
-    load_pk<NP>(hs + (size_t)y0 * rstride, t);
+    auto pix_row = [&](int row, v2s (&out)[4][NP]) {
+        const uint2* L = Lb + (size_t)row * Wp;
+        const uint2* R = Rb + (size_t)row * Wp;
+        uint2 r[NR];
 #pragma unroll
-    for (int k = 0; k < NP; k++) C[k] = t[k] * (short)(SH2 + 1);
-    for (int dy = 1; dy <= SH2; dy++) {
-        load_pk<NP>(hs + (size_t)min(y0 + dy, H - 1) * rstride, t);
+        for (int i = 0; i < NR; i++) r[i] = R[xr[i]];
 #pragma unroll
-        for (int k = 0; k < NP; k++) C[k] += t[k];
+        for (int j = 0; j < 4; j++) {
+            const uint2 l = L[xl[j]];
+            const v2s g = splat(l.x & 0xff), g0 = splat((l.x >> 8) & 0xff), g1 = splat((l.x >> 16) & 0xff);
+            const v2s w = splat(l.y & 0xff), w0 = splat((l.y >> 8) & 0xff), w1 = splat((l.y >> 16) & 0xff);
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                const int ia = j - 2 * k + 2 * NP - 1; // slot 2k (lower d); slot 2k+1 is ia - 1
+                out[j][k] = bt_pair(g, g0, g1, r[ia].x, r[ia - 1].x) + (bt_pair(w, w0, w1, r[ia].y, r[ia - 1].y) >> 2);
+            }
+        }
+    };
+
+    v2s V[4][NP], t[4][NP], Lp[4][NP];
+    int m[4] = {0, 0, 0, 0};
+    pix_row(y0, t);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int k = 0; k < NP; k++) { V[j][k] = t[j][k] * (short)(SW2 + 1); Lp[j][k] = splat(0); }
+    for (int dy = 1; dy <= SW2; dy++) {
+        pix_row(min(y0 + dy, H - 1), t);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < NP; k++) V[j][k] += t[j][k];
     }
-#pragma unroll
-    for (int k = 0; k < NP; k++) Lp[k] = splat(0);
-    int m = 0;
+    const int inf_pk = (32767 - P1) * 0x10001;
+    // tile columns that hold the first / last cost column: the horizontal window clamps there
+    const int cmin = max(-xc0, 0), cmax = min(width1 - 1 - xc0, CV_COLS - 1);
+    const size_t rstride = (size_t)width1 * D;
+    size_t orow = ((size_t)b * srows + si.off[stripe]) * rstride + d0;
+
     for (int r = 0; r < rows; r++) {
         const int y = y0 + r;
         if (r > 0) {
-            v2s a[NP];
-            load_pk<NP>(hs + (size_t)min(y + SH2, H - 1) * rstride, a);
-            load_pk<NP>(hs + (size_t)max(y - SH2 - 1, y0) * rstride, t);
+            pix_row(min(y + SW2, H - 1), t);
 #pragma unroll
-            for (int k = 0; k < NP; k++) C[k] += a[k] - t[k];
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int k = 0; k < NP; k++) V[j][k] += t[j][k];
+            pix_row(max(y - SW2 - 1, y0), t);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int k = 0; k < NP; k++) V[j][k] -= t[j][k];
         }
-        m = path_step<NP>(C, Lp, m, P1, P2, inf_pk);
-        if (active) {
-            store_pk<NP>(cost + orow, C);
-            store_pk<NP>(agg + orow, Lp);
+        int* buf = vt + (r & 1) * (CV_COLS * CS);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < NP; k++) buf[(cb + j) * CS + k * 16 + lane16] = as_int(V[j][k]);
+        __syncthreads(); // one barrier per row: the other buffer is rewritten only after the next barrier
+        v2s C[4][NP];
+#pragma unroll
+        for (int k = 0; k < NP; k++) C[0][k] = splat(0);
+        for (int dx = -SW2; dx <= SW2; dx++) {
+            const int* p = buf + min(max(cb + dx, cmin), cmax) * CS + lane16;
+#pragma unroll
+            for (int k = 0; k < NP; k++) C[0][k] += as_v2s(p[k * 16]);
+        }
+#pragma unroll
+        for (int j = 1; j < 4; j++) {
+            const int* pa = buf + min(max(cb + j + SW2, cmin), cmax) * CS + lane16;
+            const int* ps = buf + min(max(cb + j - 1 - SW2, cmin), cmax) * CS + lane16;
+#pragma unroll
+            for (int k = 0; k < NP; k++) C[j][k] = C[j - 1][k] + as_v2s(pa[k * 16]) - as_v2s(ps[k * 16]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            m[j] = path_step<NP>(C[j], Lp[j], m[j], P1, P2, inf_pk);
+            const int c = cb + j, xc = xc0 + c;
+            if (c >= SW2 && c < CV_COLS - SW2 && xc < width1) {
+                store_pk<NP>(cost + orow + (size_t)xc * D, C[j]);
+                store_pk<NP>(agg + orow + (size_t)xc * D, Lp[j]);
+            }
         }
         orow += rstride;
     }
@@ -430,14 +480,16 @@ int run_sgbm(vo_ctx* c)
     hipLaunchKernelGGL(prefilter_kernel, dim3((W + 255) / 256, H, 2 * n), dim3(256), 0, c->stream, c->img[0], c->img[1], c->pitch,
                        c->fstride, W, H, Wp, c->ftzero, reinterpret_cast<uint2*>(c->pre));
     }
-    size_t lds = (size_t)(HS_TX + 2 * SH2) * D;
-    { StageTimer st_(c, VO_ST_HSUM);
-    hipLaunchKernelGGL(hsum_kernel, dim3((w1 + HS_TX - 1) / HS_TX, H, n), dim3(256), lds, c->stream,
-                       reinterpret_cast<const uint2*>(c->pre), W, H, Wp, D, w1, SH2, c->hsum);
-    }
     { StageTimer st_(c, VO_ST_VPATH);
-    hipLaunchKernelGGL((vpath_kernel<NP>), dim3((w1 + 15) / 16, 4, n), dim3(256), 0, c->stream, c->hsum, H, w1, D, SH2, c->srows, si,
-                       c->P1, c->P2, c->cost, c->agg);
+    const size_t lds = (size_t)2 * CV_COLS * (16 * NP + 4) * sizeof(int);
+    static bool lds_attr_set = false;
+    if (lds > 48 * 1024 && !lds_attr_set) {
+        VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_vpath_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_attr_set = true;
+    }
+    const int tile_out = CV_COLS - 2 * SH2;
+    hipLaunchKernelGGL((cost_vpath_kernel<NP>), dim3((w1 + tile_out - 1) / tile_out, 4, n), dim3(256), lds, c->stream,
+                       reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D, SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg);
     }
     { StageTimer st_(c, VO_ST_HPATH_FWD);
     hipLaunchKernelGGL((hpath_kernel<NP, false>), dim3((c->srows + 15) / 16, n), dim3(256), 0, c->stream, c->cost, c->agg, w1, D, W,

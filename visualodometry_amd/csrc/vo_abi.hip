@@ -154,6 +154,7 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     CR(dalloc(&c->hyp_mask, B * c->p.ransac_chunk * F));
     c->h_stage_bytes = std::max<size_t>(B * F * (sizeof(vo_point3f) + sizeof(vo_point2f)) + B * 64, 1 << 20);
     CR(hipHostMalloc(&c->h_stage, c->h_stage_bytes, hipHostMallocDefault));
+    CR(hipHostMalloc((void**)&c->h_counts, 3 * B * sizeof(int), hipHostMallocDefault));
     c->h_nfeat.assign(B, 0); c->h_nmatch.assign(B, 0); c->h_nobj.assign(B, 0);
 #undef CR
     *out = c;
@@ -170,6 +171,8 @@ extern "C" void vo_destroy(vo_ctx* c)
                     c->obj, c->obj_img, c->n_obj, c->hyp, c->hyp_count, c->hyp_mask};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_counts) (void)hipHostFree(c->h_counts);
+    if (c->step_done) (void)hipEventDestroy(c->step_done);
     for (int i = 0; i < VO_NUM_STAGES; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -345,7 +348,7 @@ extern "C" int vo_match_klt(vo_ctx* c)
     VO_HIP(c, hipSetDevice(c->device));
     int rc;
     if (!c->have_pyr) { rc = launch_pyramids(c); if (rc) return rc; c->have_pyr = true; }
-    rc = launch_match_klt(c);
+    rc = launch_match_klt(c, true);
     if (rc) return rc;
     rc = fetch_counts(c, c->n_match, c->h_nmatch);
     if (rc) return rc;
@@ -469,38 +472,59 @@ extern "C" int vo_estimate_motion(vo_ctx* c, double* Rt_out, vo_frame_info* info
     return pnp_host::estimate_motion_batch(c, Rt_out, info);
 }
 
-extern "C" int vo_step(vo_ctx* c, double* Rt_out, vo_frame_info* info)
+extern "C" int vo_step_submit(vo_ctx* c)
 {
     CHECK_CTX(c); NEED_IMAGES(c);
     if (!c->have_calib) return vo_fail(c, VO_ERR_STATE, "calibration not set");
-    if (!Rt_out) return vo_fail(c, VO_ERR_BAD_ARG, "null output");
+    if (c->step_pending) return vo_fail(c, VO_ERR_STATE, "a submitted step has not been finished");
     VO_HIP(c, hipSetDevice(c->device));
-    const auto wall0 = std::chrono::steady_clock::now();
+    c->step_t0 = std::chrono::steady_clock::now();
     int rc;
-    // all GPU stages are enqueued back to back; the only host round trips are the feature counts
+    // every GPU stage is enqueued back to back without a host round trip
     if ((rc = launch_sgbm(c))) return rc;
     c->have_disp = true; c->have_depth = false;
     if ((rc = launch_fast(c))) return rc;
     if ((rc = launch_pyramids(c))) return rc;
     c->have_pyr = true;
-    if ((rc = fetch_counts(c, c->n_feat, c->h_nfeat))) return rc;
-    c->have_features = true;
-    if ((rc = launch_match_klt(c))) return rc;
-    c->have_matches = true;
+    if ((rc = launch_match_klt(c, false))) return rc;
     if ((rc = launch_triangulate(c))) return rc;
-    VO_HIP(c, hipMemcpyAsync(c->h_stage, c->n_match, c->n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    VO_HIP(c, hipMemcpyAsync((char*)c->h_stage + 4096, c->n_obj, c->n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    VO_HIP(c, hipStreamSynchronize(c->stream));
-    memcpy(c->h_nmatch.data(), c->h_stage, c->n * sizeof(int));
-    memcpy(c->h_nobj.data(), (char*)c->h_stage + 4096, c->n * sizeof(int));
-    c->have_obj = true;
-    rc = pnp_host::estimate_motion_batch(c, Rt_out, info);
+    VO_HIP(c, hipMemcpyAsync(c->h_counts, c->n_feat, c->n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipMemcpyAsync(c->h_counts + c->p.max_batch, c->n_match, c->n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipMemcpyAsync(c->h_counts + 2 * c->p.max_batch, c->n_obj, c->n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (!c->step_done) VO_HIP(c, hipEventCreateWithFlags(&c->step_done, hipEventDisableTiming));
+    VO_HIP(c, hipEventRecord(c->step_done, c->stream));
+    c->step_pending = true;
+    return VO_OK;
+}
+
+extern "C" int vo_step_finish(vo_ctx* c, double* Rt_out, vo_frame_info* info)
+{
+    CHECK_CTX(c);
+    if (!c->step_pending) return vo_fail(c, VO_ERR_STATE, "no submitted step");
+    if (!Rt_out) return vo_fail(c, VO_ERR_BAD_ARG, "null output");
+    VO_HIP(c, hipSetDevice(c->device));
+    c->step_pending = false;
+    VO_HIP(c, hipEventSynchronize(c->step_done));
+    memcpy(c->h_nfeat.data(), c->h_counts, c->n * sizeof(int));
+    memcpy(c->h_nmatch.data(), c->h_counts + c->p.max_batch, c->n * sizeof(int));
+    memcpy(c->h_nobj.data(), c->h_counts + 2 * c->p.max_batch, c->n * sizeof(int));
+    c->have_features = c->have_matches = c->have_obj = true;
+    int rc = pnp_host::estimate_motion_batch(c, Rt_out, info);
     if (c->timing) {
         vo_collect_timing(c);
-        c->stage_ms[VO_ST_STEP_WALL] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        c->stage_ms[VO_ST_STEP_WALL] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c->step_t0).count();
         c->stage_calls[VO_ST_STEP_WALL]++;
     }
     return rc;
+}
+
+extern "C" int vo_step(vo_ctx* c, double* Rt_out, vo_frame_info* info)
+{
+    CHECK_CTX(c);
+    if (!Rt_out) return vo_fail(c, VO_ERR_BAD_ARG, "null output");
+    int rc = vo_step_submit(c);
+    if (rc) return rc;
+    return vo_step_finish(c, Rt_out, info);
 }
 
 static const char* kStageNames[VO_NUM_STAGES] = {"sgbm_prefilter", "sgbm_hsum", "sgbm_vpath", "sgbm_hpath_fwd", "sgbm_hpath_bwd",

@@ -7,6 +7,7 @@
 #include <stddef.h>
 #include <string>
 #include <vector>
+#include <chrono>
 #include "../../include/vo_abi.h"
 
 #define VO_MAX_LEVELS 8
@@ -89,8 +90,14 @@ struct vo_ctx {
     uint8_t* hyp_mask = nullptr; // [n][chunk][max_features]
     bool have_obj = false;
 
+    // split step: GPU part enqueued, host part pending
+    bool step_pending = false;
+    hipEvent_t step_done = nullptr;
+    std::chrono::steady_clock::time_point step_t0;
+
     // pinned host staging
     void* h_stage = nullptr; size_t h_stage_bytes = 0;
+    int* h_counts = nullptr; // pinned: [3][max_batch] feature / match / object-point counts of the pending step
 
     // optional per-stage timing with HIP events on the context's stream
     bool timing = false;
@@ -120,7 +127,7 @@ int launch_fast(vo_ctx* c);
 int launch_sgbm(vo_ctx* c);
 int launch_depth_map(vo_ctx* c);
 int launch_pyramids(vo_ctx* c);
-int launch_match_klt(vo_ctx* c);
+int launch_match_klt(vo_ctx* c, bool counts_on_host);
 int launch_triangulate(vo_ctx* c);
 int launch_pnp_score(vo_ctx* c, int b0, int nb, int H, float thresh2, bool want_masks);
 
