@@ -134,6 +134,9 @@ void build_pyramid(const uint8_t* img, int w, int h, int win, int levels, bool w
     }
 }
 
+/* statistics for tuning the GPU tracker: window setups that reached the iteration loop, and iterations */
+static long long g_lk_levels = 0, g_lk_iters = 0;
+
 /* LKTrackerInvoker for one point on one level. */
 void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, orc_point2f* next_pt_io,
                  uint8_t* status, float* err, int level, int max_level, int win, int max_count, double eps2,
@@ -190,7 +193,9 @@ void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, or
     nextPt.x -= half; nextPt.y -= half;
     orc_point2f prevDelta = {0, 0};
     const int stepJ = J.stride;
+    g_lk_levels++;
     for (int j = 0; j < max_count; j++) {
+        g_lk_iters++;
         int inx = cv_floor(nextPt.x), iny = cv_floor(nextPt.y);
         if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) {
             if (level == 0) *status = 0;
@@ -324,4 +329,10 @@ extern "C" int orc_match_klt(const uint8_t* lt1, const uint8_t* rt1, const uint8
     }
     for (int i = 0; i < m; i++) { pts1_inout[i] = o1[i]; pts2_out[i] = o2[i]; }
     return m;
+}
+
+extern "C" void orc_lk_stats(long long* levels, long long* iters, int reset)
+{
+    *levels = g_lk_levels; *iters = g_lk_iters;
+    if (reset) { g_lk_levels = 0; g_lk_iters = 0; }
 }

@@ -106,15 +106,17 @@ __global__ __launch_bounds__(256) void scharr_kernel(PyrArgs pa, int level, cons
 
 // ---------------------------------------------------------------- tracker
 #define DPP_ADD(v, ctrl) ((v) + __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, false))
-// exact 64-lane sum of per-lane int32 values, as int64, identical in every lane
-__device__ __forceinline__ long long wave_sum(int v)
+// exact 64-lane sum of per-lane int32 values, returned as the float nearest to the (up to 38-bit) integer sum:
+// 16-bit halves are summed separately in 32 bits, recombined exactly in f64 and rounded to f32 once, which is what
+// a direct int64 -> float conversion gives.
+__device__ __forceinline__ float wave_sum(int v)
 {
     int lo = v & 0xffff, hi = v >> 16;
     lo = DPP_ADD(lo, 0xB1); lo = DPP_ADD(lo, 0x4E); lo = DPP_ADD(lo, 0x141); lo = DPP_ADD(lo, 0x140);
     hi = DPP_ADD(hi, 0xB1); hi = DPP_ADD(hi, 0x4E); hi = DPP_ADD(hi, 0x141); hi = DPP_ADD(hi, 0x140);
     int slo = __builtin_amdgcn_readlane(lo, 0) + __builtin_amdgcn_readlane(lo, 16) + __builtin_amdgcn_readlane(lo, 32) + __builtin_amdgcn_readlane(lo, 48);
     int shi = __builtin_amdgcn_readlane(hi, 0) + __builtin_amdgcn_readlane(hi, 16) + __builtin_amdgcn_readlane(hi, 32) + __builtin_amdgcn_readlane(hi, 48);
-    return ((long long)shi << 16) + (long long)slo;
+    return (float)((double)shi * 65536.0 + (double)slo);
 }
 
 __device__ __forceinline__ int cv_floor(float v) { return (int)floorf(v); }
@@ -136,8 +138,23 @@ __device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int
     w11 = (1 << 14) - w00 - w01 - w10;
 }
 
-// NPL = ceil(win*win / 64): window pixels per lane
-template <int NPL>
+// Window layout: a "slot" is 4 horizontally adjacent window pixels of one window row, so one 8-byte load per image
+// row feeds 4 bilinear samples (5 source bytes) instead of 16 single-byte gathers.  SEG = ceil(win/4) slots per
+// window row, win*SEG slots in all, NS = ceil(win*SEG/64) slots per lane (15x15: 1, 21x21: 2, 31x31: 4).
+__device__ __forceinline__ unsigned long long load8(const uint8_t* p)
+{
+    unsigned long long v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ int byte_of(unsigned long long v, int i) { return (int)((v >> (8 * i)) & 0xff); }
+
+__device__ __forceinline__ int blend4(int a, int b, int c, int d, int w00, int w01, int w10, int w11)
+{
+    return __mul24(a, w00) + __mul24(b, w01) + __mul24(c, w10) + __mul24(d, w11);
+}
+
+template <int NS>
 __global__ __launch_bounds__(256) void lk_kernel(LkArgs a, const uint8_t* __restrict__ pyr, const int16_t* __restrict__ der,
                                                  const vo_point2f* __restrict__ feat, const int* __restrict__ n_feat,
                                                  vo_point2f* __restrict__ legs, uint8_t* __restrict__ leg_status)
@@ -146,13 +163,15 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a, const uint8_t* __rest
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.y;
     if (i >= n_feat[b]) return; // uniform per wavefront
-    const int win = a.win, area = win * win;
+    const int win = a.win, seg = (win + 3) >> 2;
     const float half = (win - 1) * 0.5f;
-    int wx[NPL], wy[NPL];
+    int srow[NS], scol[NS], npx[NS]; // window row, first window column and number of live pixels of each slot
 #pragma unroll
-    for (int k = 0; k < NPL; k++) {
-        int p = min(lane + 64 * k, area - 1);
-        wy[k] = p / win; wx[k] = p - wy[k] * win;
+    for (int k = 0; k < NS; k++) {
+        const int t = lane + 64 * k;
+        const int r = t / seg, c = (t - r * seg) * 4;
+        npx[k] = r < win ? min(win - c, 4) : 0;
+        srow[k] = min(r, win - 1); scol[k] = c;
     }
     // legs: LT1->RT1, RT1->RT2, RT2->LT2, LT2->LT1 with image slots 0 LT1, 1 RT1, 2 LT2, 3 RT2
     const int leg_prev[4] = {0, 1, 3, 2}, leg_next[4] = {1, 3, 2, 0};
@@ -184,20 +203,28 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a, const uint8_t* __rest
             const int P = L.pitch;
             const uint8_t* I = Ibase + L.img_off + (size_t)(ipy + a.pa.border) * P + (ipx + a.pa.border);
             const int* Dv = reinterpret_cast<const int*>(Dbase + L.der_off) + (size_t)(ipy + a.pa.border) * P + (ipx + a.pa.border);
-            int Iv[NPL], Ix[NPL], Iy[NPL];
+            int off[NS];
+            int Iv[NS][4], Ix[NS][4], Iy[NS][4];
             int s11 = 0, s12 = 0, s22 = 0;
 #pragma unroll
-            for (int k = 0; k < NPL; k++) {
-                const bool on = lane + 64 * k < area;
-                const uint8_t* s = I + wy[k] * P + wx[k];
-                const int* d = Dv + wy[k] * P + wx[k];
-                int iv = descale(s[0] * w00 + s[1] * w01 + s[P] * w10 + s[P + 1] * w11, 14 - 5);
-                int d00 = d[0], d01 = d[1], d10 = d[P], d11 = d[P + 1];
-                int ixv = descale((short)d00 * w00 + (short)d01 * w01 + (short)d10 * w10 + (short)d11 * w11, 14);
-                int iyv = descale((d00 >> 16) * w00 + (d01 >> 16) * w01 + (d10 >> 16) * w10 + (d11 >> 16) * w11, 14);
-                if (!on) { iv = 0; ixv = 0; iyv = 0; }
-                Iv[k] = iv; Ix[k] = ixv; Iy[k] = iyv;
-                s11 += ixv * ixv; s12 += ixv * iyv; s22 += iyv * iyv;
+            for (int k = 0; k < NS; k++) {
+                off[k] = srow[k] * P + scol[k];
+                const unsigned long long r0 = load8(I + off[k]), r1 = load8(I + off[k] + P);
+                const int* d0 = Dv + off[k];
+                const int* d1 = d0 + P;
+                int e0[5], e1[5];
+#pragma unroll
+                for (int j = 0; j < 5; j++) { e0[j] = d0[j]; e1[j] = d1[j]; }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    // every factor fits 24 signed bits (weights <= 2^14, samples <= 2^13): full-rate 24-bit multiplies
+                    int iv = descale(blend4(byte_of(r0, j), byte_of(r0, j + 1), byte_of(r1, j), byte_of(r1, j + 1), w00, w01, w10, w11), 14 - 5);
+                    int ixv = descale(blend4((short)e0[j], (short)e0[j + 1], (short)e1[j], (short)e1[j + 1], w00, w01, w10, w11), 14);
+                    int iyv = descale(blend4(e0[j] >> 16, e0[j + 1] >> 16, e1[j] >> 16, e1[j + 1] >> 16, w00, w01, w10, w11), 14);
+                    if (j >= npx[k]) { iv = 0; ixv = 0; iyv = 0; }
+                    Iv[k][j] = iv; Ix[k][j] = ixv; Iy[k][j] = iyv;
+                    s11 += __mul24(ixv, ixv); s12 += __mul24(ixv, iyv); s22 += __mul24(iyv, iyv);
+                }
             }
             const float FLT_SCALE = 1.f / (float)(1 << 20);
             const float A11 = (float)wave_sum(s11) * FLT_SCALE, A12 = (float)wave_sum(s12) * FLT_SCALE, A22 = (float)wave_sum(s22) * FLT_SCALE;
@@ -221,10 +248,13 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a, const uint8_t* __rest
                 const uint8_t* J = Jl + (ptrdiff_t)iny * P + inx;
                 int sb1 = 0, sb2 = 0;
 #pragma unroll
-                for (int k = 0; k < NPL; k++) {
-                    const uint8_t* s = J + wy[k] * P + wx[k];
-                    int diff = descale(s[0] * w00 + s[1] * w01 + s[P] * w10 + s[P + 1] * w11, 14 - 5) - Iv[k];
-                    sb1 += diff * Ix[k]; sb2 += diff * Iy[k]; // Ix = Iy = 0 on lanes past the window
+                for (int k = 0; k < NS; k++) {
+                    const unsigned long long r0 = load8(J + off[k]), r1 = load8(J + off[k] + P);
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj++) {
+                        const int diff = descale(blend4(byte_of(r0, jj), byte_of(r0, jj + 1), byte_of(r1, jj), byte_of(r1, jj + 1), w00, w01, w10, w11), 14 - 5) - Iv[k][jj];
+                        sb1 += __mul24(diff, Ix[k][jj]); sb2 += __mul24(diff, Iy[k][jj]); // Ix = Iy = 0 past the window
+                    }
                 }
                 const float b1 = (float)wave_sum(sb1) * FLT_SCALE, b2 = (float)wave_sum(sb2) * FLT_SCALE;
                 const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
@@ -350,10 +380,10 @@ int launch_match_klt(vo_ctx* c, bool counts_on_host)
     if (nmax > 0) {
         StageTimer st_(c, VO_ST_LK);
         dim3 g((nmax + 3) / 4, c->n), blk(256);
-        const int npl = (a.win * a.win + 63) / 64;
-        if (npl <= 4) hipLaunchKernelGGL((lk_kernel<4>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
-        else if (npl <= 7) hipLaunchKernelGGL((lk_kernel<7>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
-        else hipLaunchKernelGGL((lk_kernel<16>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
+        const int ns = (a.win * ((a.win + 3) / 4) + 63) / 64;
+        if (ns <= 1) hipLaunchKernelGGL((lk_kernel<1>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
+        else if (ns <= 2) hipLaunchKernelGGL((lk_kernel<2>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
+        else hipLaunchKernelGGL((lk_kernel<4>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
     }
     StageTimer st2_(c, VO_ST_FILTER);
     hipLaunchKernelGGL(filter_kernel, dim3(c->n), dim3(256), 0, c->stream, c->feat, c->n_feat, c->p.max_features, (float)c->W, (float)c->H,

@@ -139,8 +139,8 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     CR(dalloc(&c->row_off, B * H));
     CR(dalloc(&c->n_feat, B));
     CR(dalloc(&c->feat, B * F));
-    CR(dalloc(&c->pyr, B * 4 * c->pyr_bytes));
-    CR(dalloc(&c->der, B * 4 * c->der_elems));
+    CR(dalloc(&c->pyr, B * 4 * c->pyr_bytes + 256)); // slack: the tracker reads 8 bytes where it needs 5
+    CR(dalloc(&c->der, B * 4 * c->der_elems + 64));
     CR(dalloc(&c->legs, B * 4 * F));
     CR(dalloc(&c->leg_status, B * 4 * F));
     CR(dalloc(&c->m1, B * F));
