@@ -135,7 +135,7 @@ void build_pyramid(const uint8_t* img, int w, int h, int win, int levels, bool w
 }
 
 /* statistics for tuning the GPU tracker: window setups that reached the iteration loop, and iterations */
-static long long g_lk_levels = 0, g_lk_iters = 0;
+static long long g_lk_levels = 0, g_lk_iters = 0, g_lk_hist[52];
 
 /* LKTrackerInvoker for one point on one level. */
 void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, orc_point2f* next_pt_io,
@@ -194,8 +194,9 @@ void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, or
     orc_point2f prevDelta = {0, 0};
     const int stepJ = J.stride;
     g_lk_levels++;
+    int iters_run = 0;
     for (int j = 0; j < max_count; j++) {
-        g_lk_iters++;
+        g_lk_iters++; iters_run++;
         int inx = cv_floor(nextPt.x), iny = cv_floor(nextPt.y);
         if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) {
             if (level == 0) *status = 0;
@@ -227,6 +228,7 @@ void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, or
         }
         prevDelta = delta;
     }
+    g_lk_hist[iters_run < 51 ? iters_run : 51]++;
     /* error block of the original: runs because the caller passes `err`; its bounds test can clear status */
     if (*status && level == 0) {
         orc_point2f np = {next_pt_io->x - half, next_pt_io->y - half};
@@ -335,4 +337,8 @@ extern "C" void orc_lk_stats(long long* levels, long long* iters, int reset)
 {
     *levels = g_lk_levels; *iters = g_lk_iters;
     if (reset) { g_lk_levels = 0; g_lk_iters = 0; }
+}
+extern "C" void orc_lk_hist(long long* out52, int reset)
+{
+    for (int i = 0; i < 52; i++) { out52[i] = g_lk_hist[i]; if (reset) g_lk_hist[i] = 0; }
 }

@@ -339,3 +339,31 @@ def test_edge_cases(small_seq):
         make_ctx(SMALL_W, SMALL_H, num_disparities=48)
     with pytest.raises(ValueError):
         ctx.set_images(flat[:10], flat, flat, flat)
+
+
+def test_cpp_voclass_main_loop(small_seq, tmp_path):
+    """the C++ VOClass (include/VOClass.h) driving the reference's main loop gives the oracle's trajectory"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "main_loop")
+    assert os.path.exists(exe), "run python __graft_entry__.py first"
+    seq, frames = small_seq
+    raw = tmp_path / "frames.raw"
+    with open(raw, "wb") as f:
+        f.write(("%d %d %d\n" % (SMALL_W, SMALL_H, len(frames))).encode())
+        for l, r in frames:
+            f.write(l.tobytes()); f.write(r.tobytes())
+    cal = tmp_path / "calib.txt"
+    cal.write_text(" ".join(repr(float(v)) for v in list(seq.P0.reshape(-1)) + list(seq.P1.reshape(-1))))
+    out = subprocess.run([exe, str(raw), str(cal), "64"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = np.array([[float(v) for v in line.split()] for line in out.stdout.strip().splitlines()])
+    op = ob.default_params(SMALL_W, SMALL_H, num_disparities=64)
+    pose = np.eye(4)
+    want = [np.zeros(3)]
+    for i in range(len(frames) - 1):
+        ob.step(frames[i][0], frames[i][1], frames[i + 1][0], frames[i + 1][1], op, seq.P0, seq.P1, pose)
+        want.append(pose[:3, 3].copy())
+    assert got.shape == (len(frames), 3)
+    assert np.abs(got - np.array(want)).max() < 2e-3  # 6 significant digits in the dump + pose tolerance

@@ -142,3 +142,14 @@ def test_sequence_helpers():
     assert sequence.trajectory_rmse(traj, traj) == 0.0
     est = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 1.0]]); gt = np.array([[0, 0, 0], [1, 0, 1], [2, 0, 1.0]])
     assert sequence.trajectory_rmse(est, gt) == ob.trajectory_rmse(est, gt)
+
+
+def test_cpp_voclass_example_is_built_and_links():
+    """examples/main_loop (the reference's main loop on include/VOClass.h) is built by __graft_entry__.build()."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "main_loop")
+    if not os.path.exists(exe):
+        import __graft_entry__
+        __graft_entry__.build()
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvo_amd.so")
+LIB_PATH = os.environ.get("VO_AMD_LIB") or os.path.join(_HERE, "libvo_amd.so")  # override: A/B runs of kernel variants
 _LIB = None
 
 VO_OK = 0

@@ -282,6 +282,218 @@ __global__ __launch_bounds__(256) void lk_kernel(LkArgs a, const uint8_t* __rest
     }
 }
 
+// ---------------------------------------------------------------- tracker, 16 lanes per feature
+// One DPP row (16 lanes) per feature, 4 features per wavefront, 16 per block; the four features of a wavefront
+// walk legs and levels in lockstep and iterate until the slowest has converged (lanes of finished features are
+// masked off).  A lane owns NR consecutive window rows and fetches each with one NDW-dword load; the source row
+// below its last one is the next lane's first row and arrives by a DPP row shift, so a group loads every source
+// row once.  Pixels are kept as 16-bit pairs (p[x], p[x+1]) and weights as 16-bit pairs, so one bilinear sample
+// is two v_dot2_i32_i16; the rounding constant and the template value ride in the accumulator operand:
+//     diff = (J00*w00 + J01*w01 + J10*w10 + J11*w11 + 2^8 - (I << 9)) >> 9        (exact: I << 9 is a multiple of 2^9)
+// The mismatch vector uses dot2 on pairs of diffs against pairs of Ix (Iy).  Sums are integers, so the order of
+// accumulation is free; the 16-lane reduction is 4 DPP row adds on 16-bit halves, recombined exactly in f64.
+typedef short lk_v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int dot2(int a, int b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_v2s, a), __builtin_bit_cast(lk_v2s, b), c, false);
+}
+__device__ __forceinline__ int from_next_lane(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x101, 0xF, 0xF, false); }
+__device__ __forceinline__ int pack_lo16(int lo, int hi) { return (int)__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
+
+// exact sum over the 16 lanes of a group, as the float nearest to the integer (every lane gets it)
+__device__ __forceinline__ float group_sum(int v)
+{
+    int lo = v & 0xffff, hi = v >> 16;
+    lo = DPP_ADD(lo, 0xB1); lo = DPP_ADD(lo, 0x4E); lo = DPP_ADD(lo, 0x141); lo = DPP_ADD(lo, 0x140);
+    hi = DPP_ADD(hi, 0xB1); hi = DPP_ADD(hi, 0x4E); hi = DPP_ADD(hi, 0x141); hi = DPP_ADD(hi, 0x140);
+    return (float)((double)hi * 65536.0 + (double)lo);
+}
+
+// the 4*NDW-1 pairs (p[x], p[x+1]) of one source row, each as two zero-extended 16-bit halves
+template <int NDW>
+__device__ __forceinline__ void pixel_pairs(const uint8_t* __restrict__ p, int (&pr)[4 * NDW - 1])
+{
+    unsigned w[NDW];
+    __builtin_memcpy(w, p, 4 * NDW);
+#pragma unroll
+    for (int px = 0; px < 4 * NDW - 1; px++) {
+        const int q = px >> 2, o = px & 3, q1 = q + 1 < NDW ? q + 1 : q;
+        pr[px] = (int)__builtin_amdgcn_perm(o == 3 ? w[q1] : w[q], w[q], 0x0c000c00u | (unsigned)o | ((unsigned)(o + 1) << 16));
+    }
+}
+// the same for a derivative row: pairs (Ix[x], Ix[x+1]) and (Iy[x], Iy[x+1])
+template <int NDW>
+__device__ __forceinline__ void deriv_pairs(const int* __restrict__ p, int (&dx)[4 * NDW - 1], int (&dy)[4 * NDW - 1])
+{
+    unsigned e[4 * NDW];
+    __builtin_memcpy(e, p, 16 * NDW);
+#pragma unroll
+    for (int px = 0; px < 4 * NDW - 1; px++) {
+        dx[px] = (int)__builtin_amdgcn_perm(e[px + 1], e[px], 0x05040100u);
+        dy[px] = (int)__builtin_amdgcn_perm(e[px + 1], e[px], 0x07060302u);
+    }
+}
+
+template <int NR, int NDW>
+__global__ __launch_bounds__(256) void lk_row_kernel(LkArgs a, const uint8_t* __restrict__ pyr, const int16_t* __restrict__ der,
+                                                     const vo_point2f* __restrict__ feat, const int* __restrict__ n_feat,
+                                                     vo_point2f* __restrict__ legs, uint8_t* __restrict__ leg_status)
+{
+    constexpr int NPX = 4 * NDW - 1;   // pixel slots per window row (win <= NPX)
+    constexpr int NPP = 2 * NDW;       // slot pairs per window row
+    const int lane16 = threadIdx.x & 15;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int b = blockIdx.y;
+    const int nf = n_feat[b];
+    if (blockIdx.x * 16 + (int)(threadIdx.x >> 6) * 4 >= nf) return; // uniform per wavefront
+    const bool have = i < nf;
+    const int win = a.win;
+    const float half = (win - 1) * 0.5f;
+    const int row0 = lane16 * NR;
+    const int leg_prev[4] = {0, 1, 3, 2}, leg_next[4] = {1, 3, 2, 0};
+    vo_point2f prev0 = feat[(size_t)b * a.max_features + min(i, nf - 1)];
+    const int nl = a.pa.nlevels;
+    const float FLT_SCALE = 1.f / (float)(1 << 20);
+
+    for (int leg = 0; leg < 4; leg++) {
+        const uint8_t* Ibase = pyr + ((size_t)b * 4 + leg_prev[leg]) * a.pa.pyr_bytes;
+        const uint8_t* Jbase = pyr + ((size_t)b * 4 + leg_next[leg]) * a.pa.pyr_bytes;
+        const int16_t* Dbase = der + ((size_t)b * 4 + leg_prev[leg]) * a.pa.der_elems;
+        float nx = 0.f, ny = 0.f;
+        int status = 1;
+        for (int level = nl; level >= 0; level--) {
+            const LevelArgs L = a.pa.lv[level];
+            const int P = L.pitch;
+            const float sc = 1.f / (float)(1 << level);
+            float px = prev0.x * sc, py = prev0.y * sc;
+            float qx, qy;
+            if (level == nl) { qx = px; qy = py; }
+            else { qx = nx * 2.f; qy = ny * 2.f; }
+            nx = qx; ny = qy;
+            px -= half; py -= half;
+            const int ipx = cv_floor(px), ipy = cv_floor(py);
+            bool run = have;
+            if (ipx < -win || ipx >= L.w || ipy < -win || ipy >= L.h) {
+                if (level == 0) status = 0;
+                run = false;
+            }
+            int rowoff[NR];
+#pragma unroll
+            for (int k = 0; k < NR; k++) rowoff[k] = min(row0 + k, win) * P;
+            int C0[NR][NPX], IxP[NR][NPP], IyP[NR][NPP];
+            float A11 = 0.f, A12 = 0.f, A22 = 0.f, Dt = 0.f;
+            if (run) {
+                int w00, w01, w10, w11;
+                bilinear_weights(px - ipx, py - ipy, w00, w01, w10, w11);
+                const int w0 = (w00 & 0xffff) | (w01 << 16), w1 = (w10 & 0xffff) | (w11 << 16);
+                const uint8_t* I = Ibase + L.img_off + (size_t)(ipy + a.pa.border) * P + (ipx + a.pa.border);
+                const int* Dv = reinterpret_cast<const int*>(Dbase + L.der_off) + (size_t)(ipy + a.pa.border) * P + (ipx + a.pa.border);
+                int pr[NR + 1][NPX], dx[NR + 1][NPX], dy[NR + 1][NPX];
+#pragma unroll
+                for (int k = 0; k < NR; k++) {
+                    pixel_pairs<NDW>(I + rowoff[k], pr[k]);
+                    deriv_pairs<NDW>(Dv + rowoff[k], dx[k], dy[k]);
+                }
+#pragma unroll
+                for (int x = 0; x < NPX; x++) {
+                    pr[NR][x] = from_next_lane(pr[0][x]); dx[NR][x] = from_next_lane(dx[0][x]); dy[NR][x] = from_next_lane(dy[0][x]);
+                }
+                int s11 = 0, s12 = 0, s22 = 0;
+#pragma unroll
+                for (int k = 0; k < NR; k++) {
+                    const bool live = row0 + k < win;
+                    const int wd0 = live ? w0 : 0, wd1 = live ? w1 : 0; // a dead row gets zero derivatives
+                    int ixv[NPX + 1], iyv[NPX + 1];
+#pragma unroll
+                    for (int x = 0; x < NPX; x++) {
+                        const int iv = dot2(pr[k + 1][x], w1, dot2(pr[k][x], w0, 1 << 8)) >> 9;
+                        C0[k][x] = (1 << 8) - (iv << 9);
+                        ixv[x] = dot2(dx[k + 1][x], wd1, dot2(dx[k][x], wd0, 1 << 13)) >> 14;
+                        iyv[x] = dot2(dy[k + 1][x], wd1, dot2(dy[k][x], wd0, 1 << 13)) >> 14;
+                    }
+                    ixv[NPX] = 0; iyv[NPX] = 0;
+#pragma unroll
+                    for (int p = 0; p < NPP; p++) {
+                        const int m = 2 * p + 1 < win ? -1 : (2 * p < win ? 0xffff : 0); // slots past the window are zero
+                        IxP[k][p] = pack_lo16(ixv[2 * p], ixv[2 * p + 1]) & m;
+                        IyP[k][p] = pack_lo16(iyv[2 * p], iyv[2 * p + 1]) & m;
+                        s11 = dot2(IxP[k][p], IxP[k][p], s11); s12 = dot2(IxP[k][p], IyP[k][p], s12); s22 = dot2(IyP[k][p], IyP[k][p], s22);
+                    }
+                }
+                A11 = group_sum(s11) * FLT_SCALE; A12 = group_sum(s12) * FLT_SCALE; A22 = group_sum(s22) * FLT_SCALE;
+                Dt = A11 * A22 - A12 * A12;
+                const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
+                if (minEig < a.min_eig || Dt < 1.1920929e-07f) {
+                    if (level == 0) status = 0;
+                    run = false;
+                }
+                Dt = 1.f / Dt;
+            }
+            qx -= half; qy -= half;
+            float pdx = 0.f, pdy = 0.f;
+            const uint8_t* Jl = Jbase + L.img_off + (size_t)a.pa.border * P + a.pa.border;
+            bool it = run && a.max_count > 0;
+            int j = 0;
+            while (__any(it)) {
+                if (it) {
+                    const int inx = cv_floor(qx), iny = cv_floor(qy);
+                    if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) {
+                        if (level == 0) status = 0;
+                        it = false;
+                    } else {
+                        int w00, w01, w10, w11;
+                        bilinear_weights(qx - inx, qy - iny, w00, w01, w10, w11);
+                        const int w0 = (w00 & 0xffff) | (w01 << 16), w1 = (w10 & 0xffff) | (w11 << 16);
+                        const uint8_t* J = Jl + (ptrdiff_t)iny * P + inx;
+                        int pr[NR + 1][NPX];
+#pragma unroll
+                        for (int k = 0; k < NR; k++) pixel_pairs<NDW>(J + rowoff[k], pr[k]);
+#pragma unroll
+                        for (int x = 0; x < NPX; x++) pr[NR][x] = from_next_lane(pr[0][x]);
+                        int sb1 = 0, sb2 = 0;
+#pragma unroll
+                        for (int k = 0; k < NR; k++) {
+                            int d[NPX + 1];
+#pragma unroll
+                            for (int x = 0; x < NPX; x++) d[x] = dot2(pr[k + 1][x], w1, dot2(pr[k][x], w0, C0[k][x])) >> 9;
+                            d[NPX] = 0;
+#pragma unroll
+                            for (int p = 0; p < NPP; p++) {
+                                // the last pair has no upper slot: its Ix/Iy halves are zero, whatever the upper 16 bits of d hold
+                                const int dp = 2 * p + 1 < NPX ? pack_lo16(d[2 * p], d[2 * p + 1]) : d[2 * p];
+                                sb1 = dot2(dp, IxP[k][p], sb1); sb2 = dot2(dp, IyP[k][p], sb2);
+                            }
+                        }
+                        const float b1 = group_sum(sb1) * FLT_SCALE, b2 = group_sum(sb2) * FLT_SCALE;
+                        const float dx_ = (A12 * b2 - A22 * b1) * Dt, dy_ = (A12 * b1 - A11 * b2) * Dt;
+                        qx += dx_; qy += dy_;
+                        nx = qx + half; ny = qy + half;
+                        if ((double)dx_ * (double)dx_ + (double)dy_ * (double)dy_ <= a.eps2) it = false;
+                        else if (j > 0 && (double)fabsf(dx_ + pdx) < 0.01 && (double)fabsf(dy_ + pdy) < 0.01) {
+                            nx -= dx_ * 0.5f; ny -= dy_ * 0.5f;
+                            it = false;
+                        }
+                        pdx = dx_; pdy = dy_;
+                    }
+                }
+                j++;
+                if (j >= a.max_count) it = false;
+            }
+            if (status && level == 0) {
+                // the error pass of the original re-tests the final window position and can clear the status
+                const int inx = cv_floor(nx - half), iny = cv_floor(ny - half);
+                if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) status = 0;
+            }
+        }
+        if (have && lane16 == 0) {
+            vo_point2f o; o.x = nx; o.y = ny;
+            legs[((size_t)b * 4 + leg) * a.max_features + i] = o;
+            leg_status[((size_t)b * 4 + leg) * a.max_features + i] = (uint8_t)status;
+        }
+        prev0.x = nx; prev0.y = ny;
+    }
+}
+
 // ---------------------------------------------------------------- circular-match filter
 __global__ __launch_bounds__(256) void filter_kernel(const vo_point2f* __restrict__ feat, const int* __restrict__ n_feat, int max_features,
                                                      float fw, float fh, int loop_thr, const vo_point2f* __restrict__ legs,
@@ -379,11 +591,18 @@ int launch_match_klt(vo_ctx* c, bool counts_on_host)
     if (counts_on_host) for (int b = 0; b < c->n; b++) nmax = std::max(nmax, c->h_nfeat[b]);
     if (nmax > 0) {
         StageTimer st_(c, VO_ST_LK);
+#ifndef VO_LK_WAVE
+        dim3 g16((nmax + 15) / 16, c->n), blk16(256);
+        if (a.win <= 15) hipLaunchKernelGGL((lk_row_kernel<1, 4>), g16, blk16, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
+        else if (a.win <= 23) hipLaunchKernelGGL((lk_row_kernel<2, 6>), g16, blk16, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
+        else hipLaunchKernelGGL((lk_row_kernel<2, 8>), g16, blk16, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
+#else
         dim3 g((nmax + 3) / 4, c->n), blk(256);
         const int ns = (a.win * ((a.win + 3) / 4) + 63) / 64;
         if (ns <= 1) hipLaunchKernelGGL((lk_kernel<1>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
         else if (ns <= 2) hipLaunchKernelGGL((lk_kernel<2>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
         else hipLaunchKernelGGL((lk_kernel<4>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
+#endif
     }
     StageTimer st2_(c, VO_ST_FILTER);
     hipLaunchKernelGGL(filter_kernel, dim3(c->n), dim3(256), 0, c->stream, c->feat, c->n_feat, c->p.max_features, (float)c->W, (float)c->H,

@@ -284,7 +284,10 @@ __global__ __launch_bounds__(256) void cost_vpath_kernel(const uint2* __restrict
 }
 
 // ---------------------------------------------------------------- horizontal paths
-constexpr int HP_U = 4; // steps per prefetch group
+#ifndef VO_HP_U
+#define VO_HP_U 4
+#endif
+constexpr int HP_U = VO_HP_U; // steps per prefetch group
 
 template <int NP, bool BACKWARD>
 __global__ __launch_bounds__(256) void hpath_kernel(const int16_t* __restrict__ cost, int16_t* __restrict__ agg, int width1, int D,
