@@ -42,20 +42,28 @@ def stripe_rows(H, block=11):
     return sum(max(min((s + 1) * sz, H) - max(min(s * sz - overlap, H), 0), 0) for s in range(4))
 
 
+def pyramid_pixels(W, H, levels=4):
+    pyr, w, h = 0, W, H
+    for _ in range(levels):
+        pyr += w * h
+        w, h = (w + 1) // 2, (h + 1) // 2
+    return pyr
+
+
 def kernel_bytes(W, H, D, srows, nframes):
-    """Compulsory (algorithmic) bytes each SGBM kernel moves per launch: every input and output counted once."""
+    """Compulsory (algorithmic) bytes each kernel moves per launch: every input and output counted once."""
     w1 = W - D
-    vol_h = H * w1 * D * 2          # horizontal window sums, one row per image row
-    vol_s = srows * w1 * D * 2      # per-stripe-row volumes (aggregated cost, path sums)
+    vol_s = srows * w1 * D * 2      # one per-stripe-row s16 volume (cost, path sums)
     P = W * H
+    pyr = pyramid_pixels(W, H)
     per = {
         "sgbm_prefilter": 2 * P + 2 * P * 8,
-        "sgbm_hsum": 2 * P * 8 + vol_h,
-        "sgbm_vpath": vol_h + 2 * vol_s,
-        "sgbm_hpath_fwd": 2 * vol_s + vol_s,
-        "sgbm_hpath_bwd": 2 * vol_s + srows * W * 4,
+        "sgbm_vpath": 2 * P * 8 + 2 * vol_s,            # prefiltered rows in; C and L_top out
+        "sgbm_hpath_fwd": 2 * vol_s + vol_s,            # C, L_top in; L_lr + L_top out
+        "sgbm_hpath_bwd": 2 * vol_s + srows * W * 4,    # C, path sum in; packed winner out
         "sgbm_lrcheck": srows * W * 4 + P * 2,
         "sgbm_median": P * 2 + P * 2 + P * 4,
+        "lk": 4 * (pyr + 4 * pyr + pyr),                # 4 legs x (previous image + its derivatives + next image)
     }
     return {k: v * nframes for k, v in per.items()}
 
@@ -64,10 +72,7 @@ def frame_bytes(W, H, D, n_feat=4000):
     """Algorithmic bytes per stereo frame of the whole path: A = A_io + A_cv (one write + one read of the
     aggregated s16 cost volume), with P = W*H, Pyr = pixels of pyramid levels 0..3, C = H*(W-D)*D."""
     P = W * H
-    pyr, w, h = 0, W, H
-    for _ in range(4):
-        pyr += w * h
-        w, h = (w + 1) // 2, (h + 1) // 2
+    pyr = pyramid_pixels(W, H)
     C = H * (W - D) * D
     a_io = 2 * P + (2 * P + 2 * P) + (P + 8 * n_feat) + 2 * pyr + 2 * (pyr + 4 * pyr) + 4 * (pyr + 4 * pyr + pyr)
     a_cv = 2 * 2 * C

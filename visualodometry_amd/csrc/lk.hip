@@ -11,10 +11,11 @@
 //                    (sum + 128) >> 8; reads the bordered previous level, so no edge cases.
 //  border_kernel   : fills the border of a level by reflection.
 //  scharr_kernel   : 3x3 Scharr of a level (from its bordered image), zero outside.
-//  lk_kernel       : one wavefront per feature runs all four legs LT1->RT1->RT2->LT2->LT1 and all pyramid
-//                    levels; the win x win window is spread over the 64 lanes, the 2x2 structure tensor and
-//                    the mismatch vector are accumulated in integers (order independent) and reduced with DPP
-//                    row adds + readlane; the 2x2 solve is replicated per lane in f32 without contraction.
+//  lk_row_kernel   : 16 lanes per feature (4 features per wavefront) run all four legs LT1->RT1->RT2->LT2->LT1
+//                    and all pyramid levels; a lane owns one or two window rows, the 2x2 structure tensor and
+//                    the mismatch vector are accumulated in integers (order independent) with 16-bit dot
+//                    products and reduced with DPP row adds; the 2x2 solve is replicated per lane in f32
+//                    without contraction.
 //  filter_kernel   : bounds filter per leg, 4-way status AND, loop-closure test, ordered compaction.
 #include "vo_ctx.h"
 #include <string.h>
@@ -104,24 +105,9 @@ __global__ __launch_bounds__(256) void scharr_kernel(PyrArgs pa, int level, cons
     out[(size_t)py * L.pitch + px] = (ix & 0xffff) | (iy << 16);
 }
 
-// ---------------------------------------------------------------- tracker
 #define DPP_ADD(v, ctrl) ((v) + __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, false))
-// exact 64-lane sum of per-lane int32 values, returned as the float nearest to the (up to 38-bit) integer sum:
-// 16-bit halves are summed separately in 32 bits, recombined exactly in f64 and rounded to f32 once, which is what
-// a direct int64 -> float conversion gives.
-__device__ __forceinline__ float wave_sum(int v)
-{
-    int lo = v & 0xffff, hi = v >> 16;
-    lo = DPP_ADD(lo, 0xB1); lo = DPP_ADD(lo, 0x4E); lo = DPP_ADD(lo, 0x141); lo = DPP_ADD(lo, 0x140);
-    hi = DPP_ADD(hi, 0xB1); hi = DPP_ADD(hi, 0x4E); hi = DPP_ADD(hi, 0x141); hi = DPP_ADD(hi, 0x140);
-    int slo = __builtin_amdgcn_readlane(lo, 0) + __builtin_amdgcn_readlane(lo, 16) + __builtin_amdgcn_readlane(lo, 32) + __builtin_amdgcn_readlane(lo, 48);
-    int shi = __builtin_amdgcn_readlane(hi, 0) + __builtin_amdgcn_readlane(hi, 16) + __builtin_amdgcn_readlane(hi, 32) + __builtin_amdgcn_readlane(hi, 48);
-    return (float)((double)shi * 65536.0 + (double)slo);
-}
-
 __device__ __forceinline__ int cv_floor(float v) { return (int)floorf(v); }
 __device__ __forceinline__ int cv_round(float v) { return __float2int_rn(v); }
-__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
 struct LkArgs {
     PyrArgs pa;
@@ -136,150 +122,6 @@ __device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int
     w01 = cv_round(a * (1.f - b) * (float)(1 << 14));
     w10 = cv_round((1.f - a) * b * (float)(1 << 14));
     w11 = (1 << 14) - w00 - w01 - w10;
-}
-
-// Window layout: a "slot" is 4 horizontally adjacent window pixels of one window row, so one 8-byte load per image
-// row feeds 4 bilinear samples (5 source bytes) instead of 16 single-byte gathers.  SEG = ceil(win/4) slots per
-// window row, win*SEG slots in all, NS = ceil(win*SEG/64) slots per lane (15x15: 1, 21x21: 2, 31x31: 4).
-__device__ __forceinline__ unsigned long long load8(const uint8_t* p)
-{
-    unsigned long long v;
-    __builtin_memcpy(&v, p, 8);
-    return v;
-}
-__device__ __forceinline__ int byte_of(unsigned long long v, int i) { return (int)((v >> (8 * i)) & 0xff); }
-
-__device__ __forceinline__ int blend4(int a, int b, int c, int d, int w00, int w01, int w10, int w11)
-{
-    return __mul24(a, w00) + __mul24(b, w01) + __mul24(c, w10) + __mul24(d, w11);
-}
-
-template <int NS>
-__global__ __launch_bounds__(256) void lk_kernel(LkArgs a, const uint8_t* __restrict__ pyr, const int16_t* __restrict__ der,
-                                                 const vo_point2f* __restrict__ feat, const int* __restrict__ n_feat,
-                                                 vo_point2f* __restrict__ legs, uint8_t* __restrict__ leg_status)
-{
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int b = blockIdx.y;
-    if (i >= n_feat[b]) return; // uniform per wavefront
-    const int win = a.win, seg = (win + 3) >> 2;
-    const float half = (win - 1) * 0.5f;
-    int srow[NS], scol[NS], npx[NS]; // window row, first window column and number of live pixels of each slot
-#pragma unroll
-    for (int k = 0; k < NS; k++) {
-        const int t = lane + 64 * k;
-        const int r = t / seg, c = (t - r * seg) * 4;
-        npx[k] = r < win ? min(win - c, 4) : 0;
-        srow[k] = min(r, win - 1); scol[k] = c;
-    }
-    // legs: LT1->RT1, RT1->RT2, RT2->LT2, LT2->LT1 with image slots 0 LT1, 1 RT1, 2 LT2, 3 RT2
-    const int leg_prev[4] = {0, 1, 3, 2}, leg_next[4] = {1, 3, 2, 0};
-    vo_point2f prev0 = feat[(size_t)b * a.max_features + i];
-    const int nl = a.pa.nlevels;
-
-    for (int leg = 0; leg < 4; leg++) {
-        const uint8_t* Ibase = pyr + ((size_t)b * 4 + leg_prev[leg]) * a.pa.pyr_bytes;
-        const uint8_t* Jbase = pyr + ((size_t)b * 4 + leg_next[leg]) * a.pa.pyr_bytes;
-        const int16_t* Dbase = der + ((size_t)b * 4 + leg_prev[leg]) * a.pa.der_elems;
-        float nx = 0.f, ny = 0.f; // nextPts entry
-        int status = 1;
-        for (int level = nl; level >= 0; level--) {
-            const LevelArgs L = a.pa.lv[level];
-            const float sc = 1.f / (float)(1 << level);
-            float px = prev0.x * sc, py = prev0.y * sc;
-            float qx, qy;
-            if (level == nl) { qx = px; qy = py; }
-            else { qx = nx * 2.f; qy = ny * 2.f; }
-            nx = qx; ny = qy;
-            px -= half; py -= half;
-            const int ipx = cv_floor(px), ipy = cv_floor(py);
-            if (ipx < -win || ipx >= L.w || ipy < -win || ipy >= L.h) {
-                if (level == 0) status = 0;
-                continue;
-            }
-            int w00, w01, w10, w11;
-            bilinear_weights(px - ipx, py - ipy, w00, w01, w10, w11);
-            const int P = L.pitch;
-            const uint8_t* I = Ibase + L.img_off + (size_t)(ipy + a.pa.border) * P + (ipx + a.pa.border);
-            const int* Dv = reinterpret_cast<const int*>(Dbase + L.der_off) + (size_t)(ipy + a.pa.border) * P + (ipx + a.pa.border);
-            int off[NS];
-            int Iv[NS][4], Ix[NS][4], Iy[NS][4];
-            int s11 = 0, s12 = 0, s22 = 0;
-#pragma unroll
-            for (int k = 0; k < NS; k++) {
-                off[k] = srow[k] * P + scol[k];
-                const unsigned long long r0 = load8(I + off[k]), r1 = load8(I + off[k] + P);
-                const int* d0 = Dv + off[k];
-                const int* d1 = d0 + P;
-                int e0[5], e1[5];
-#pragma unroll
-                for (int j = 0; j < 5; j++) { e0[j] = d0[j]; e1[j] = d1[j]; }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    // every factor fits 24 signed bits (weights <= 2^14, samples <= 2^13): full-rate 24-bit multiplies
-                    int iv = descale(blend4(byte_of(r0, j), byte_of(r0, j + 1), byte_of(r1, j), byte_of(r1, j + 1), w00, w01, w10, w11), 14 - 5);
-                    int ixv = descale(blend4((short)e0[j], (short)e0[j + 1], (short)e1[j], (short)e1[j + 1], w00, w01, w10, w11), 14);
-                    int iyv = descale(blend4(e0[j] >> 16, e0[j + 1] >> 16, e1[j] >> 16, e1[j + 1] >> 16, w00, w01, w10, w11), 14);
-                    if (j >= npx[k]) { iv = 0; ixv = 0; iyv = 0; }
-                    Iv[k][j] = iv; Ix[k][j] = ixv; Iy[k][j] = iyv;
-                    s11 += __mul24(ixv, ixv); s12 += __mul24(ixv, iyv); s22 += __mul24(iyv, iyv);
-                }
-            }
-            const float FLT_SCALE = 1.f / (float)(1 << 20);
-            const float A11 = (float)wave_sum(s11) * FLT_SCALE, A12 = (float)wave_sum(s12) * FLT_SCALE, A22 = (float)wave_sum(s22) * FLT_SCALE;
-            float Dt = A11 * A22 - A12 * A12;
-            const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
-            if (minEig < a.min_eig || Dt < 1.1920929e-07f) {
-                if (level == 0) status = 0;
-                continue;
-            }
-            Dt = 1.f / Dt;
-            qx -= half; qy -= half;
-            float pdx = 0.f, pdy = 0.f;
-            const uint8_t* Jl = Jbase + L.img_off + (size_t)a.pa.border * P + a.pa.border;
-            for (int j = 0; j < a.max_count; j++) {
-                const int inx = cv_floor(qx), iny = cv_floor(qy);
-                if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) {
-                    if (level == 0) status = 0;
-                    break;
-                }
-                bilinear_weights(qx - inx, qy - iny, w00, w01, w10, w11);
-                const uint8_t* J = Jl + (ptrdiff_t)iny * P + inx;
-                int sb1 = 0, sb2 = 0;
-#pragma unroll
-                for (int k = 0; k < NS; k++) {
-                    const unsigned long long r0 = load8(J + off[k]), r1 = load8(J + off[k] + P);
-#pragma unroll
-                    for (int jj = 0; jj < 4; jj++) {
-                        const int diff = descale(blend4(byte_of(r0, jj), byte_of(r0, jj + 1), byte_of(r1, jj), byte_of(r1, jj + 1), w00, w01, w10, w11), 14 - 5) - Iv[k][jj];
-                        sb1 += __mul24(diff, Ix[k][jj]); sb2 += __mul24(diff, Iy[k][jj]); // Ix = Iy = 0 past the window
-                    }
-                }
-                const float b1 = (float)wave_sum(sb1) * FLT_SCALE, b2 = (float)wave_sum(sb2) * FLT_SCALE;
-                const float dx = (A12 * b2 - A22 * b1) * Dt, dy = (A12 * b1 - A11 * b2) * Dt;
-                qx += dx; qy += dy;
-                nx = qx + half; ny = qy + half;
-                if ((double)dx * (double)dx + (double)dy * (double)dy <= a.eps2) break;
-                if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
-                    nx -= dx * 0.5f; ny -= dy * 0.5f;
-                    break;
-                }
-                pdx = dx; pdy = dy;
-            }
-            if (status && level == 0) {
-                // the error pass of the original re-tests the final window position and can clear the status
-                const int inx = cv_floor(nx - half), iny = cv_floor(ny - half);
-                if (inx < -win || inx >= L.w || iny < -win || iny >= L.h) status = 0;
-            }
-        }
-        if (lane == 0) {
-            vo_point2f o; o.x = nx; o.y = ny;
-            legs[((size_t)b * 4 + leg) * a.max_features + i] = o;
-            leg_status[((size_t)b * 4 + leg) * a.max_features + i] = (uint8_t)status;
-        }
-        prev0.x = nx; prev0.y = ny;
-    }
 }
 
 // ---------------------------------------------------------------- tracker, 16 lanes per feature
@@ -297,7 +139,14 @@ __device__ __forceinline__ int dot2(int a, int b, int c)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_v2s, a), __builtin_bit_cast(lk_v2s, b), c, false);
 }
-__device__ __forceinline__ int from_next_lane(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x101, 0xF, 0xF, false); }
+// first product of a chain whose addend must stay live: the saturating form never saturates here (|sum| < 2^31) but
+// it is the three-operand encoding, so the addend needs no copy
+__device__ __forceinline__ int dot2_keep(int a, int b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_v2s, a), __builtin_bit_cast(lk_v2s, b), c, true);
+}
+// lane i takes lane i+1's value; the last lane of a group gets 0 (it owns no live window row that needs it)
+__device__ __forceinline__ int from_next_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true); }
 __device__ __forceinline__ int pack_lo16(int lo, int hi) { return (int)__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
 
 // exact sum over the 16 lanes of a group, as the float nearest to the integer (every lane gets it)
@@ -307,6 +156,26 @@ __device__ __forceinline__ float group_sum(int v)
     lo = DPP_ADD(lo, 0xB1); lo = DPP_ADD(lo, 0x4E); lo = DPP_ADD(lo, 0x141); lo = DPP_ADD(lo, 0x140);
     hi = DPP_ADD(hi, 0xB1); hi = DPP_ADD(hi, 0x4E); hi = DPP_ADD(hi, 0x141); hi = DPP_ADD(hi, 0x140);
     return (float)((double)hi * 65536.0 + (double)lo);
+}
+
+// two sums at once: four independent DPP chains, stepped together so no step waits on the previous one
+__device__ __forceinline__ void group_sum2(int u, int v, float& su, float& sv)
+{
+    int c[4] = {u & 0xffff, u >> 16, v & 0xffff, v >> 16};
+#pragma unroll
+    for (int s = 0; s < 4; s++) { // the DPP control must be a literal, hence the chain of selects on the unrolled step
+        int t[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            t[q] = s == 0 ? __builtin_amdgcn_update_dpp(0, c[q], 0xB1, 0xF, 0xF, false)
+                 : s == 1 ? __builtin_amdgcn_update_dpp(0, c[q], 0x4E, 0xF, 0xF, false)
+                 : s == 2 ? __builtin_amdgcn_update_dpp(0, c[q], 0x141, 0xF, 0xF, false)
+                          : __builtin_amdgcn_update_dpp(0, c[q], 0x140, 0xF, 0xF, false);
+#pragma unroll
+        for (int q = 0; q < 4; q++) c[q] += t[q];
+    }
+    su =(float)((double)c[1] * 65536.0 + (double)c[0]);
+    sv = (float)((double)c[3] * 65536.0 + (double)c[2]);
 }
 
 // the 4*NDW-1 pairs (p[x], p[x+1]) of one source row, each as two zero-extended 16-bit halves
@@ -455,7 +324,7 @@ __global__ __launch_bounds__(256) void lk_row_kernel(LkArgs a, const uint8_t* __
                         for (int k = 0; k < NR; k++) {
                             int d[NPX + 1];
 #pragma unroll
-                            for (int x = 0; x < NPX; x++) d[x] = dot2(pr[k + 1][x], w1, dot2(pr[k][x], w0, C0[k][x])) >> 9;
+                            for (int x = 0; x < NPX; x++) d[x] = dot2(pr[k + 1][x], w1, dot2_keep(pr[k][x], w0, C0[k][x])) >> 9;
                             d[NPX] = 0;
 #pragma unroll
                             for (int p = 0; p < NPP; p++) {
@@ -464,7 +333,9 @@ __global__ __launch_bounds__(256) void lk_row_kernel(LkArgs a, const uint8_t* __
                                 sb1 = dot2(dp, IxP[k][p], sb1); sb2 = dot2(dp, IyP[k][p], sb2);
                             }
                         }
-                        const float b1 = group_sum(sb1) * FLT_SCALE, b2 = group_sum(sb2) * FLT_SCALE;
+                        float b1, b2;
+                        group_sum2(sb1, sb2, b1, b2);
+                        b1 *= FLT_SCALE; b2 *= FLT_SCALE;
                         const float dx_ = (A12 * b2 - A22 * b1) * Dt, dy_ = (A12 * b1 - A11 * b2) * Dt;
                         qx += dx_; qy += dy_;
                         nx = qx + half; ny = qy + half;
@@ -591,18 +462,10 @@ int launch_match_klt(vo_ctx* c, bool counts_on_host)
     if (counts_on_host) for (int b = 0; b < c->n; b++) nmax = std::max(nmax, c->h_nfeat[b]);
     if (nmax > 0) {
         StageTimer st_(c, VO_ST_LK);
-#ifndef VO_LK_WAVE
         dim3 g16((nmax + 15) / 16, c->n), blk16(256);
         if (a.win <= 15) hipLaunchKernelGGL((lk_row_kernel<1, 4>), g16, blk16, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
         else if (a.win <= 23) hipLaunchKernelGGL((lk_row_kernel<2, 6>), g16, blk16, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
         else hipLaunchKernelGGL((lk_row_kernel<2, 8>), g16, blk16, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
-#else
-        dim3 g((nmax + 3) / 4, c->n), blk(256);
-        const int ns = (a.win * ((a.win + 3) / 4) + 63) / 64;
-        if (ns <= 1) hipLaunchKernelGGL((lk_kernel<1>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
-        else if (ns <= 2) hipLaunchKernelGGL((lk_kernel<2>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
-        else hipLaunchKernelGGL((lk_kernel<4>), g, blk, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
-#endif
     }
     StageTimer st2_(c, VO_ST_FILTER);
     hipLaunchKernelGGL(filter_kernel, dim3(c->n), dim3(256), 0, c->stream, c->feat, c->n_feat, c->p.max_features, (float)c->W, (float)c->H,
