@@ -8,11 +8,10 @@
 //
 //  prefilter_kernel : per pixel and image, the two Birchfield-Tomasi channels (clipped x-Sobel, raw) with
 //                     their half-pixel min/max, packed into 8 bytes.
-//  hsum_kernel      : pixel cost of a row tile into LDS (one evaluation per cell), then the 11-wide
-//                     horizontal window sum, clamped at the ends of the cost row.
-//  vpath_kernel     : 16 lanes x (D/16) disparities per cost column, 4 columns per wavefront, marching down
-//                     the stripe: running 11-row vertical window sum -> aggregated cost C, top-down path L_top.
-//                     The minimum over D is a DPP row reduction; d-1 / d+1 neighbours come from DPP row shifts.
+//  cost_vpath_kernel: 16 lanes x (D/16) disparities per cost column, 4 columns per lane group, 64 columns per block,
+//                     marching down the stripe: pixel cost, running vertical window sum, horizontal window sum
+//                     through LDS -> aggregated cost C, top-down path L_top.  The minimum over D is a DPP row
+//                     reduction; d-1 / d+1 neighbours come from DPP row shifts.
 //  hpath_kernel     : 16 lanes per image row, 4 rows per wavefront, serial along x with register prefetch.
 //                     forward: L_lr, stores L_lr + L_top.  backward: L_rl, S = sum of the three paths,
 //                     winner-take-all with OpenCV's tie rule, sub-pixel fit, packed (minS, d16) per pixel.
@@ -104,14 +103,20 @@ __global__ __launch_bounds__(256) void prefilter_kernel(const uint8_t* __restric
 // u, u0, u1: the left pixel's value / half-pixel min / max, splatted.  ra, rb: the right pixels for the
 // lower and the upper disparity of the pair, bytes (v, v0, v1, -).
 __device__ __forceinline__ v2s vmax(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
+typedef unsigned short v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s sub_sat0(v2s a, v2s b)
+{
+    return __builtin_bit_cast(v2s, __builtin_elementwise_sub_sat(__builtin_bit_cast(v2u, a), __builtin_bit_cast(v2u, b)));
+}
 __device__ __forceinline__ v2s bt_pair(v2s u, v2s u0, v2s u1, unsigned ra, unsigned rb)
 {
     const v2s v = as_v2s((int)__builtin_amdgcn_perm(rb, ra, 0x0c040c00u));
     const v2s v0 = as_v2s((int)__builtin_amdgcn_perm(rb, ra, 0x0c050c01u));
     const v2s v1 = as_v2s((int)__builtin_amdgcn_perm(rb, ra, 0x0c060c02u));
-    const v2s zero = splat(0);
-    const v2s c0 = vmax(vmax(zero, u - v1), v0 - u);
-    const v2s c1 = vmax(vmax(zero, v - u1), u0 - v);
+    // all operands are in [0, 255]: max(0, a - b) is an unsigned saturating subtract, and of the two one-sided
+    // distances of an interval at most one is non-zero
+    const v2s c0 = vmax(sub_sat0(u, v1), sub_sat0(v0, u));
+    const v2s c1 = vmax(sub_sat0(v, u1), sub_sat0(u0, v));
     return vmin(c0, c1);
 }
 
@@ -160,18 +165,21 @@ __device__ __forceinline__ void store_pk(int16_t* __restrict__ p, const v2s (&v)
 struct StripeInfo { int y0[4], rows[4], off[4]; };
 
 // ---------------------------------------------------------------- pixel cost + 11x11 window + top-down path, fused
-// Block = 256 threads = 16 lane groups x 16 lanes; a lane group owns 4 adjacent tile columns (64 per block,
+// Block = VO_COST_THREADS threads in lane groups of 16; a lane group owns 4 adjacent tile columns (CV_COLS per block,
 // SW2 of them on each side are halo), a lane 2*NP consecutive disparities of each.  Marching down the stripe:
-//   V(x, d)  = running vertical window sum of the pixel cost (both the entering and the leaving image row are
-//              re-evaluated from the prefiltered rows: no cost ring buffer, no cost volume read back),
+//   V(x, d)  = running vertical window sum of the pixel cost.  The row that enters the window is evaluated from the
+//              prefiltered rows; the row that leaves it was evaluated block_size steps earlier by the same thread and
+//              comes back from a per-thread ring of byte costs in global memory (a cost is at most 30 + 63, so 4 cells
+//              per dword; the ring has block_size + 1 slots so the slot read and the slot written always differ),
 //   C(x, d)  = horizontal window sum of V through LDS (sliding over the group's 4 columns),
 //   L_top    = one path step per column; C and L_top are the only HBM traffic (one write each).
-constexpr int CV_COLS = 64;
+constexpr int CV_COLS = VO_COST_TILE_COLS;
 
-template <int NP>
-__global__ __launch_bounds__(256) void cost_vpath_kernel(const uint2* __restrict__ pre, int W, int H, int Wp, int width1, int D, int SW2,
+// SWC: the half window as a compile-time constant (0 = use the run-time SW2; slower horizontal sum)
+template <int NP, int SWC>
+__global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2* __restrict__ pre, int W, int H, int Wp, int width1, int D, int SW2,
                                                          int srows, StripeInfo si, int P1, int P2, int16_t* __restrict__ cost,
-                                                         int16_t* __restrict__ agg)
+                                                         int16_t* __restrict__ agg, uint32_t* __restrict__ ring)
 {
     extern __shared__ int vt[]; // [2][CV_COLS][CS]: V of every tile column, dword (k, lane16) at k*16 + lane16
     constexpr int CS = 16 * NP + 4;
@@ -187,24 +195,24 @@ __global__ __launch_bounds__(256) void cost_vpath_kernel(const uint2* __restrict
     const int d0 = lane16 * 2 * NP;
     const uint2* Lb = pre + ((size_t)b * 2 + 0) * H * Wp;
     const uint2* Rb = pre + ((size_t)b * 2 + 1) * H * Wp;
-    int xl[4];
+    unsigned xl[4]; // unsigned byte offsets from a uniform row pointer: scalar base + 32-bit lane offset addressing
 #pragma unroll
-    for (int j = 0; j < 4; j++) xl[j] = minX1 + min(max(xc0 + cb + j, 0), width1 - 1);
+    for (int j = 0; j < 4; j++) xl[j] = 8u * (unsigned)(minX1 + min(max(xc0 + cb + j, 0), width1 - 1));
     // right pixel of (column j, slot s) is r[j - s + 2NP - 1] with r[i] = R[xr0 + i]
     const int xr0 = minX1 + xc0 + cb - d0 - (2 * NP - 1);
-    int xr[NR];
+    unsigned xr[NR];
 #pragma unroll
-    for (int i = 0; i < NR; i++) xr[i] = min(max(xr0 + i, 0), W - 1);
+    for (int i = 0; i < NR; i++) xr[i] = 8u * (unsigned)min(max(xr0 + i, 0), W - 1);
 
     auto pix_row = [&](int row, v2s (&out)[4][NP]) {
-        const uint2* L = Lb + (size_t)row * Wp;
-        const uint2* R = Rb + (size_t)row * Wp;
+        const char* L = reinterpret_cast<const char*>(Lb + (size_t)row * Wp);
+        const char* R = reinterpret_cast<const char*>(Rb + (size_t)row * Wp);
         uint2 r[NR];
 #pragma unroll
-        for (int i = 0; i < NR; i++) r[i] = R[xr[i]];
+        for (int i = 0; i < NR; i++) r[i] = *reinterpret_cast<const uint2*>(R + xr[i]);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint2 l = L[xl[j]];
+            const uint2 l = *reinterpret_cast<const uint2*>(L + xl[j]);
             const v2s g = splat(l.x & 0xff), g0 = splat((l.x >> 8) & 0xff), g1 = splat((l.x >> 16) & 0xff);
             const v2s w = splat(l.y & 0xff), w0 = splat((l.y >> 8) & 0xff), w1 = splat((l.y >> 16) & 0xff);
 #pragma unroll
@@ -215,6 +223,30 @@ __global__ __launch_bounds__(256) void cost_vpath_kernel(const uint2* __restrict
         }
     };
 
+    // ring of evaluated rows: slot s, dword w of thread tid at ((blk * nslot + s) * 2NP + w) * VO_COST_THREADS + tid
+    const int nslot = 2 * SW2 + 2;
+    uint32_t* rg = ring + ((size_t)((b * 4 + stripe) * gridDim.x + blockIdx.x) * nslot) * (2 * NP * VO_COST_THREADS); // uniform
+    const unsigned tid = threadIdx.x;
+    auto ring_put = [&](int slot, const v2s (&src)[4][NP]) {
+        uint32_t* q_ = rg + (size_t)slot * (2 * NP * VO_COST_THREADS);
+#pragma unroll
+        for (int w = 0; w < 2 * NP; w++) { // cells (2w, 2w+1) of the thread's 4 x NP pairs, low bytes
+            const int a0 = 2 * w, a1 = 2 * w + 1;
+            q_[w * VO_COST_THREADS + tid] = __builtin_amdgcn_perm((unsigned)as_int(src[a1 / NP][a1 % NP]), (unsigned)as_int(src[a0 / NP][a0 % NP]), 0x06040200u);
+        }
+    };
+    auto ring_get = [&](int slot, v2s (&dst)[4][NP]) {
+        const uint32_t* q_ = rg + (size_t)slot * (2 * NP * VO_COST_THREADS);
+#pragma unroll
+        for (int w = 0; w < 2 * NP; w++) {
+            const unsigned v = q_[w * VO_COST_THREADS + tid];
+            const int a0 = 2 * w, a1 = 2 * w + 1;
+            dst[a0 / NP][a0 % NP] = as_v2s((int)__builtin_amdgcn_perm(0u, v, 0x0c010c00u));
+            dst[a1 / NP][a1 % NP] = as_v2s((int)__builtin_amdgcn_perm(0u, v, 0x0c030c02u));
+        }
+    };
+
+    // window rows are numbered relative to the stripe top; rows above it repeat row 0.  Row q lives in slot (q + nslot) % nslot.
     v2s V[4][NP], t[4][NP], Lp[4][NP];
     int m[4] = {0, 0, 0, 0};
     pix_row(y0, t);
@@ -222,8 +254,10 @@ __global__ __launch_bounds__(256) void cost_vpath_kernel(const uint2* __restrict
     for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int k = 0; k < NP; k++) { V[j][k] = t[j][k] * (short)(SW2 + 1); Lp[j][k] = splat(0); }
+    for (int q = -SW2; q <= 0; q++) ring_put((q + nslot) % nslot, t);
     for (int dy = 1; dy <= SW2; dy++) {
-        pix_row(min(y0 + dy, H - 1), t);
+        if (y0 + dy <= H - 1) pix_row(y0 + dy, t); // past the last image row the last row repeats: t already holds it
+        ring_put(dy, t);
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -232,22 +266,32 @@ __global__ __launch_bounds__(256) void cost_vpath_kernel(const uint2* __restrict
     const int inf_pk = (32767 - P1) * 0x10001;
     // tile columns that hold the first / last cost column: the horizontal window clamps there
     const int cmin = max(-xc0, 0), cmax = min(width1 - 1 - xc0, CV_COLS - 1);
+    constexpr int NC = 4 + 2 * (SWC > 0 ? SWC : 1);
+    int cidx[NC];
+#pragma unroll
+    for (int i = 0; i < NC; i++) cidx[i] = min(max(cb - SWC + i, cmin), cmax) * CS + lane16;
     const size_t rstride = (size_t)width1 * D;
-    size_t orow = ((size_t)b * srows + si.off[stripe]) * rstride + d0;
+    // output addressing: uniform row pointers + a 32-bit byte offset per owned column (~0 = not stored: halo or past the row)
+    char* crow = reinterpret_cast<char*>(cost + ((size_t)b * srows + si.off[stripe]) * rstride);
+    char* arow = reinterpret_cast<char*>(agg + ((size_t)b * srows + si.off[stripe]) * rstride);
+    unsigned ocol[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int c = cb + j, xc = xc0 + c;
+        ocol[j] = (c >= SW2 && c < CV_COLS - SW2 && xc < width1) ? (unsigned)((xc * D + d0) * (int)sizeof(int16_t)) : ~0u;
+    }
 
     for (int r = 0; r < rows; r++) {
         const int y = y0 + r;
         if (r > 0) {
-            pix_row(min(y + SW2, H - 1), t);
+            v2s gone[4][NP];
+            ring_get((r - SW2 - 1 + nslot) % nslot, gone);      // row r - SW2 - 1 leaves the window
+            if (y + SW2 <= H - 1) pix_row(y + SW2, t);          // row r + SW2 enters it (the last image row repeats)
+            ring_put((r + SW2) % nslot, t);
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int k = 0; k < NP; k++) V[j][k] += t[j][k];
-            pix_row(max(y - SW2 - 1, y0), t);
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int k = 0; k < NP; k++) V[j][k] -= t[j][k];
+                for (int k = 0; k < NP; k++) V[j][k] += t[j][k] - gone[j][k];
         }
         int* buf = vt + (r & 1) * (CV_COLS * CS);
 #pragma unroll
@@ -256,30 +300,51 @@ __global__ __launch_bounds__(256) void cost_vpath_kernel(const uint2* __restrict
             for (int k = 0; k < NP; k++) buf[(cb + j) * CS + k * 16 + lane16] = as_int(V[j][k]);
         __syncthreads(); // one barrier per row: the other buffer is rewritten only after the next barrier
         v2s C[4][NP];
+        if (SWC > 0) {
+            // compile-time window: the group's 4 windows span 4 + 2*SWC columns; every column is read once, at an
+            // LDS offset that does not depend on the row (clamped at the ends of the cost row)
+            v2s col[NC][NP];
 #pragma unroll
-        for (int k = 0; k < NP; k++) C[0][k] = splat(0);
-        for (int dx = -SW2; dx <= SW2; dx++) {
-            const int* p = buf + min(max(cb + dx, cmin), cmax) * CS + lane16;
+            for (int i = 0; i < NC; i++) {
+                const int* p = buf + cidx[i];
 #pragma unroll
-            for (int k = 0; k < NP; k++) C[0][k] += as_v2s(p[k * 16]);
-        }
+                for (int k = 0; k < NP; k++) col[i][k] = as_v2s(p[k * 16]);
+            }
 #pragma unroll
-        for (int j = 1; j < 4; j++) {
-            const int* pa = buf + min(max(cb + j + SW2, cmin), cmax) * CS + lane16;
-            const int* ps = buf + min(max(cb + j - 1 - SW2, cmin), cmax) * CS + lane16;
+            for (int k = 0; k < NP; k++) {
+                v2s a = col[0][k];
 #pragma unroll
-            for (int k = 0; k < NP; k++) C[j][k] = C[j - 1][k] + as_v2s(pa[k * 16]) - as_v2s(ps[k * 16]);
-        }
+                for (int i = 1; i <= 2 * SWC; i++) a += col[i][k];
+                C[0][k] = a;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            m[j] = path_step<NP>(C[j], Lp[j], m[j], P1, P2, inf_pk);
-            const int c = cb + j, xc = xc0 + c;
-            if (c >= SW2 && c < CV_COLS - SW2 && xc < width1) {
-                store_pk<NP>(cost + orow + (size_t)xc * D, C[j]);
-                store_pk<NP>(agg + orow + (size_t)xc * D, Lp[j]);
+                for (int j = 1; j < 4; j++) C[j][k] = C[j - 1][k] + col[j + 2 * SWC][k] - col[j - 1][k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NP; k++) C[0][k] = splat(0);
+            for (int dx = -SW2; dx <= SW2; dx++) {
+                const int* p = buf + min(max(cb + dx, cmin), cmax) * CS + lane16;
+#pragma unroll
+                for (int k = 0; k < NP; k++) C[0][k] += as_v2s(p[k * 16]);
+            }
+#pragma unroll
+            for (int j = 1; j < 4; j++) {
+                const int* pa = buf + min(max(cb + j + SW2, cmin), cmax) * CS + lane16;
+                const int* ps = buf + min(max(cb + j - 1 - SW2, cmin), cmax) * CS + lane16;
+#pragma unroll
+                for (int k = 0; k < NP; k++) C[j][k] = C[j - 1][k] + as_v2s(pa[k * 16]) - as_v2s(ps[k * 16]);
             }
         }
-        orow += rstride;
+#pragma unroll
+        for (int j = 0; j < 4; j++) m[j] = path_step<NP>(C[j], Lp[j], m[j], P1, P2, inf_pk); // four independent chains
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (ocol[j] != ~0u) {
+                store_pk<NP>(reinterpret_cast<int16_t*>(crow + ocol[j]), C[j]);
+                store_pk<NP>(reinterpret_cast<int16_t*>(arow + ocol[j]), Lp[j]);
+            }
+        }
+        crow += rstride * sizeof(int16_t); arow += rstride * sizeof(int16_t);
     }
 }
 
@@ -484,15 +549,23 @@ int run_sgbm(vo_ctx* c)
                        c->fstride, W, H, Wp, c->ftzero, reinterpret_cast<uint2*>(c->pre));
     }
     { StageTimer st_(c, VO_ST_VPATH);
+    // the reference's window (11x11, Source/VOClass.cpp:242) gets the instantiation with a compile-time half window
+    const int swc = SH2 == 5 ? 5 : 0;
     const size_t lds = (size_t)2 * CV_COLS * (16 * NP + 4) * sizeof(int);
-    static bool lds_attr_set = false;
-    if (lds > 48 * 1024 && !lds_attr_set) {
-        VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&cost_vpath_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_attr_set = true;
+    const void* fn = swc ? reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 5>) : reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 0>);
+    static bool lds_attr_set[2] = {false, false};
+    if (lds > 48 * 1024 && !lds_attr_set[swc ? 1 : 0]) {
+        VO_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_attr_set[swc ? 1 : 0] = true;
     }
     const int tile_out = CV_COLS - 2 * SH2;
-    hipLaunchKernelGGL((cost_vpath_kernel<NP>), dim3((w1 + tile_out - 1) / tile_out, 4, n), dim3(256), lds, c->stream,
-                       reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D, SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg);
+    const dim3 grid((w1 + tile_out - 1) / tile_out, 4, n), blk(VO_COST_THREADS);
+    if (swc)
+        hipLaunchKernelGGL((cost_vpath_kernel<NP, 5>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
+                           SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring);
+    else
+        hipLaunchKernelGGL((cost_vpath_kernel<NP, 0>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
+                           SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring);
     }
     { StageTimer st_(c, VO_ST_HPATH_FWD);
     hipLaunchKernelGGL((hpath_kernel<NP, false>), dim3((c->srows + 15) / 16, n), dim3(256), 0, c->stream, c->cost, c->agg, w1, D, W,

@@ -126,7 +126,7 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     c->own_pitch = (W + 63) & ~(size_t)63; c->own_fstride = c->own_pitch * H;
     CR(dalloc(&c->img_own, 4 * B * c->own_fstride));
     CR(dalloc(&c->pre, B * 2 * H * W * 8));
-    CR(dalloc(&c->hsum, B * H * w1 * D));
+    CR(dalloc(&c->ring, B * 4 * vo_cost_tiles(c) * (c->p.block_size + 1) * (D / 16) * VO_COST_THREADS));
     CR(dalloc(&c->cost, B * c->srows * w1 * D));
     CR(dalloc(&c->agg, B * c->srows * w1 * D));
     CR(dalloc(&c->wta, B * c->srows * W));
@@ -166,7 +166,7 @@ extern "C" void vo_destroy(vo_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->img_own, c->pre, c->hsum, c->cost, c->agg, c->wta, c->disp_pre, c->disp16, c->disp32, c->depth, c->score,
+    void* bufs[] = {c->img_own, c->pre, c->ring, c->cost, c->agg, c->wta, c->disp_pre, c->disp16, c->disp32, c->depth, c->score,
                     c->row_count, c->row_off, c->n_feat, c->feat, c->pyr, c->der, c->legs, c->leg_status, c->m1, c->m2, c->n_match,
                     c->obj, c->obj_img, c->n_obj, c->hyp, c->hyp_count, c->hyp_mask};
     for (void* b : bufs) if (b) (void)hipFree(b);

@@ -50,7 +50,7 @@ struct vo_ctx {
 
     // ---- SGBM ----
     uint8_t* pre = nullptr;      // prefiltered rows: [n][2 images][H][Wp] x 8 bytes (g,g0,g1,r,r0,r1,0,0)
-    int16_t* hsum = nullptr;     // [n][H][width1][D]
+    uint32_t* ring = nullptr;    // pixel-cost rows in flight of the cost kernel: [n][4 stripes][x tiles][block_size + 1][D / 16][256]
     int16_t* cost = nullptr;     // [n][srows][width1][D]
     int16_t* agg = nullptr;      // [n][srows][width1][D]  L_top, then L_top + L_lr
     int32_t* wta = nullptr;      // [n][srows][W] packed (minS << 16) | (d16 & 0xffff)
@@ -121,6 +121,18 @@ int vo_fail(vo_ctx* c, int code, const char* fmt, ...);
         hipError_t e__ = (call);                                                                  \
         if (e__ != hipSuccess) return vo_fail((c), VO_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
     } while (0)
+
+// cost kernel tiling: a block of VO_COST_THREADS threads covers VO_COST_TILE_COLS cost columns (4 per 16-lane
+// group), block_size / 2 of them halo on each side
+#ifndef VO_COST_THREADS
+#define VO_COST_THREADS 256
+#endif
+constexpr int VO_COST_TILE_COLS = VO_COST_THREADS / 4;
+inline size_t vo_cost_tiles(const vo_ctx* c)
+{
+    const int tile_out = VO_COST_TILE_COLS - 2 * (c->p.block_size / 2);
+    return (size_t)((c->width1 + tile_out - 1) / tile_out);
+}
 
 // ---- launchers (each enqueues on c->stream, returns a vo_status) ----
 int launch_fast(vo_ctx* c);
