@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--inflight", type=int, default=2, help="contexts taking turns (overlaps host PnP with GPU work)")
+    ap.add_argument("--mode", default="pairs", choices=["pairs", "sequence"],
+                    help="pairs: B independent frame pairs, 4 pyramids each (what the reference rebuilds per step); "
+                         "sequence: B + 1 consecutive frames, every frame pyramided once")
     args = ap.parse_args()
 
     import torch
@@ -141,7 +144,13 @@ def main():
         arr = np.stack([frames[(b % nd) + shift][which] for b in range(B)])
         return torch.from_numpy(arr).to(dev)
 
-    lt1, rt1, lt2, rt2 = tiled(0, 0), tiled(1, 0), tiled(0, 1), tiled(1, 1)  # resident in HBM before timing starts
+    if args.mode == "pairs":
+        lt1, rt1, lt2, rt2 = tiled(0, 0), tiled(1, 0), tiled(0, 1), tiled(1, 1)  # resident in HBM before timing starts
+    else:
+        # B + 1 consecutive frames: walk the rendered frames forth and back so that every pair is a real motion
+        walk = [m if m <= nd else 2 * nd - m for m in (k % (2 * nd) for k in range(B + 1))]
+        left = torch.from_numpy(np.stack([frames[w][0] for w in walk])).to(dev)
+        right = torch.from_numpy(np.stack([frames[w][1] for w in walk])).to(dev)
 
     p = abi.default_params(W, H, max_batch=B, num_disparities=D, lk_win=shape["lk_win"], max_features=shape["max_features"],
                            host_threads=args.host_threads)
@@ -151,7 +160,10 @@ def main():
     for _ in range(max(1, args.inflight)):
         c = abi.Context(p, local_rank)
         c.set_calib(seq.P0, seq.P1)
-        c.set_images_device(B, [t.data_ptr() for t in (lt1, rt1, lt2, rt2)], W, W * H, keep=(lt1, rt1, lt2, rt2))
+        if args.mode == "pairs":
+            c.set_images_device(B, [t.data_ptr() for t in (lt1, rt1, lt2, rt2)], W, W * H, keep=(lt1, rt1, lt2, rt2))
+        else:
+            c.set_sequence_device(B, left.data_ptr(), right.data_ptr(), W, W * H, keep=(left, right))
         ctxs.append(c)
     ctx = ctxs[0]
     nctx = len(ctxs)
@@ -228,7 +240,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s-shape synthetic stereo, %dx%d, %d disparities, %d frame pairs per step per GPU, whole hot path "
                                    "(SGBM-3way + FAST + circular KLT + triangulation + PnP-RANSAC)" % (args.workload, W, H, D, B),
-                       "batch": B, "batches_in_flight": nctx, "sharding": "independent sequences, one per GPU; poses all-gathered once (RCCL)",
+                       "batch": B, "batches_in_flight": nctx, "input_mode": args.mode, "sharding": "independent sequences, one per GPU; poses all-gathered once (RCCL)",
                        "mpix_per_s": fps * W * H / 1e6,
                        "features_per_frame": int(np.mean([i.n_features for i in info])),
                        "matches_per_frame": int(np.mean([i.n_matched for i in info])),

@@ -115,6 +115,16 @@ int vo_set_images(vo_ctx* ctx, int n, const uint8_t* lt1, const uint8_t* rt1, co
 int vo_set_images_device(vo_ctx* ctx, int n, const uint8_t* lt1, const uint8_t* rt1, const uint8_t* lt2,
                          const uint8_t* rt2, size_t stride, size_t frame_stride);
 
+/* n_pairs + 1 consecutive frames of one sequence (left[f], right[f] at f * frame_stride): pair b is
+ * (frame b, frame b + 1), i.e. what n_pairs iterations of the reference's main loop read one after the other
+ * (Source/main.cpp:36-39, Source/VOClass.cpp:36-83, which re-reads frame t+1 as the next step's frame t).
+ * Results are identical to vo_set_images with the four shifted arrays; every frame is uploaded once and its
+ * pyramid and derivatives are built once instead of twice. */
+int vo_set_sequence(vo_ctx* ctx, int n_pairs, const uint8_t* left, const uint8_t* right, size_t stride,
+                    size_t frame_stride);
+int vo_set_sequence_device(vo_ctx* ctx, int n_pairs, const uint8_t* left, const uint8_t* right, size_t stride,
+                           size_t frame_stride);
+
 /* VOClass::computeDisparity(imgLT1, imgRT1) (Source/VOClass.cpp:231-305): StereoSGBM 3-way + median,
  * s16 x16 map and its /16 float form, for all n frames. */
 int vo_compute_disparity(vo_ctx* ctx);

@@ -1,0 +1,96 @@
+"""KITTI on-disk formats (calib.txt, poses, PNG frames, pose dump, depth .ply) as the reference reads / writes them:
+Source/VOClass.cpp:36-226,613-615, Source/VOClassUtils.cpp:6-59,111-157."""
+import os
+
+import numpy as np
+import pytest
+
+from visualodometry_amd import kitti, synth
+
+KITTI00_CALIB = (
+    "P0: 7.188560000000e+02 0.000000000000e+00 6.071928000000e+02 0.000000000000e+00 0.000000000000e+00 7.188560000000e+02 "
+    "1.852157000000e+02 0.000000000000e+00 0.000000000000e+00 0.000000000000e+00 1.000000000000e+00 0.000000000000e+00\n"
+    "P1: 7.188560000000e+02 0.000000000000e+00 6.071928000000e+02 -3.861448000000e+02 0.000000000000e+00 7.188560000000e+02 "
+    "1.852157000000e+02 0.000000000000e+00 0.000000000000e+00 0.000000000000e+00 1.000000000000e+00 0.000000000000e+00\n"
+    "P2: 1 2 3 4 5 6 7 8 9 10 11 12\n")
+
+
+def test_calib_known_answer(tmp_path):
+    p = tmp_path / "calib.txt"
+    p.write_text(KITTI00_CALIB)
+    P0, P1 = kitti.read_calib(str(p))
+    assert P0.shape == (3, 4) and P0[0, 0] == 718.856 and P0[0, 2] == 607.1928 and P0[1, 2] == 185.2157 and P0[2, 2] == 1.0
+    assert P1[0, 3] == -386.1448 and np.array_equal(P0[:, :3], P1[:, :3])
+    # baseline as computeDepthMap derives it (Source/VOClass.cpp:318)
+    assert abs(P1[0, 3] / (-1 * P0[0, 0]) - 0.53716) < 1e-5
+    (tmp_path / "bad.txt").write_text("P0: 1 2 3\nP1: 1 2 3\n")
+    with pytest.raises(ValueError):
+        kitti.read_calib(str(tmp_path / "bad.txt"))
+
+
+def test_poses_and_ground_truth(tmp_path):
+    p = tmp_path / "00.txt"
+    p.write_text("1 0 0 0 0 1 0 0 0 0 1 0\n"
+                 "9.999978e-01 5.272628e-04 -2.066935e-03 -4.690294e-02 -5.296506e-04 9.999992e-01 -1.154865e-03 -2.839928e-02 "
+                 "2.066324e-03 1.155958e-03 9.999971e-01 8.586941e-01\n")
+    poses = kitti.read_poses(str(p))
+    assert poses.shape == (2, 3, 4)
+    gt = kitti.ground_truth(poses)
+    assert np.array_equal(gt[0], [0, 0, 0]) and np.array_equal(gt[1], [-4.690294e-02, -2.839928e-02, 8.586941e-01])
+    kitti.write_poses(str(tmp_path / "w.txt"), poses)
+    assert np.allclose(kitti.read_poses(str(tmp_path / "w.txt")), poses, rtol=1e-9, atol=0)
+
+
+def test_trajectory_dump_has_six_significant_digits(tmp_path):
+    traj = np.array([[0, 0, 0], [-0.0469029412, 1234567.0, 0.858694123], [1e-7, -2.5, 100.0]])
+    kitti.write_trajectory_xyz(str(tmp_path / "t.txt"), traj)
+    lines = (tmp_path / "t.txt").read_text().splitlines()
+    assert lines == ["0 0 0", "-0.0469029 1.23457e+06 0.858694", "1e-07 -2.5 100"]   # what `ostream << double` prints
+    assert np.allclose(kitti.read_trajectory_xyz(str(tmp_path / "t.txt")), traj, rtol=1e-5)
+
+
+def test_png_round_trip_every_filter(tmp_path):
+    rng = np.random.RandomState(3)
+    img = rng.randint(0, 256, size=(37, 53)).astype(np.uint8)
+    img[5:20, 10:40] = np.arange(30, dtype=np.uint8)[None, :] * 3   # smooth area: non-trivial Sub/Paeth predictions
+    for ft in range(5):
+        path = str(tmp_path / ("f%d.png" % ft))
+        kitti.write_png_gray(path, img, filter_type=ft)
+        assert np.array_equal(kitti.read_png_gray(path), img), ft
+    try:
+        from PIL import Image
+    except Exception:
+        return
+    for ft in range(5):   # an independent decoder reads our files, and ours reads its files (grey and RGB)
+        assert np.array_equal(np.array(Image.open(str(tmp_path / ("f%d.png" % ft)))), img)
+    Image.fromarray(img).save(str(tmp_path / "pil.png"))
+    assert np.array_equal(kitti.read_png_gray(str(tmp_path / "pil.png")), img)
+    rgb = rng.randint(0, 256, size=(9, 11, 3)).astype(np.uint8)
+    Image.fromarray(rgb).save(str(tmp_path / "rgb.png"))
+    want = ((rgb[..., 0].astype(int) * 4899 + rgb[..., 1].astype(int) * 9617 + rgb[..., 2].astype(int) * 1868 + 8192) >> 14).astype(np.uint8)
+    assert np.array_equal(kitti.read_png_gray(str(tmp_path / "rgb.png")), want)
+
+
+def test_sequence_directory_layout(tmp_path):
+    seq = synth.Sequence(seed=5, width=96, height=40)
+    frames = [seq.frame(i) for i in range(3)]
+    poses = [np.hstack([np.eye(3), seq.pose(i)[:3, 3:4]]) for i in range(3)]
+    kitti.write_sequence(str(tmp_path), frames, seq.P0, seq.P1, poses=poses)
+    assert sorted(os.listdir(str(tmp_path / "image_0"))) == ["000000.png", "000001.png", "000002.png"]
+    ks = kitti.Sequence(str(tmp_path), str(tmp_path / "poses.txt"))
+    assert len(ks) == 3 and np.allclose(ks.P0, seq.P0) and np.allclose(ks.P1, seq.P1)
+    for i in range(3):
+        l, r = ks.frame(i)
+        assert np.array_equal(l, frames[i][0]) and np.array_equal(r, frames[i][1])
+    assert kitti.ground_truth(ks.poses).shape == (3, 3)
+
+
+def test_depth_ply_matches_the_reference_writer(tmp_path):
+    depth = np.array([[10.5, 3861.448], [2999.9999, 3861.448], [3000.0, 7.25]])
+    gray = np.array([[1, 2], [3, 4], [5, 6]], dtype=np.uint8)
+    written, header = kitti.write_depth_ply(str(tmp_path / "d.ply"), depth, gray)
+    lines = (tmp_path / "d.ply").read_text().splitlines()
+    assert lines[:3] == ["ply", "format ascii 1.0", "element vertex 4"] and lines[9] == "end_header"
+    assert written == header == 4
+    # float(2999.9999) == 3000.0f, which is not > 3000: kept, printed with 6 significant digits
+    assert lines[10:] == ["0 0 -10.5 1 1 1", "1 0 -3000 3 3 3", "2 0 -3000 5 5 5", "2 1 -7.25 6 6 6"]

@@ -19,7 +19,8 @@ TAP_FAST_SCORE, TAP_DISP_PREMEDIAN, TAP_COST_ROW, TAP_PYR_LEVEL, TAP_DERIV_LEVEL
 # every symbol declared in include/vo_abi.h
 EXPORTS = (
     "vo_default_params", "vo_create", "vo_destroy", "vo_last_error", "vo_create_error", "vo_stream", "vo_synchronize",
-    "vo_set_calib", "vo_set_images", "vo_set_images_device", "vo_compute_disparity", "vo_get_disparity16",
+    "vo_set_calib", "vo_set_images", "vo_set_images_device", "vo_set_sequence", "vo_set_sequence_device",
+    "vo_compute_disparity", "vo_get_disparity16",
     "vo_get_disparity32", "vo_compute_depth_map", "vo_get_depth", "vo_detect_fast", "vo_get_features", "vo_set_features",
     "vo_match_klt", "vo_get_matches", "vo_get_klt_legs", "vo_set_matches", "vo_triangulate", "vo_get_object_points",
     "vo_pnp_score", "vo_estimate_motion", "vo_integrate_pose", "vo_step", "vo_step_submit", "vo_step_finish", "vo_read_tap", "vo_pyramid_info",
@@ -77,6 +78,8 @@ def lib():
         L.vo_destroy.restype = None
         for name in ("vo_set_images", "vo_set_images_device"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+        for name in ("vo_set_sequence", "vo_set_sequence_device"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         L.vo_read_tap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.vo_pnp_score.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         _LIB = L
@@ -154,6 +157,22 @@ class Context:
         self._keep = keep
         self._check(self._L.vo_set_images_device(self._h, int(n), *[C.c_void_p(int(p)) for p in ptrs], int(stride), int(frame_stride)))
         self.n = int(n)
+
+    def set_sequence(self, left, right):
+        """Host images of n + 1 consecutive frames ((n+1) x H x W uint8 each): pair b is (frame b, frame b + 1)."""
+        left = np.ascontiguousarray(left, dtype=np.uint8)
+        right = np.ascontiguousarray(right, dtype=np.uint8)
+        if left.ndim != 3 or left.shape != right.shape or left.shape[1:] != (self.H, self.W) or left.shape[0] < 2:
+            raise ValueError("expected two (n+1) x H x W arrays")
+        n = left.shape[0] - 1
+        self._check(self._L.vo_set_sequence(self._h, n, _ptr(left), _ptr(right), self.W, self.W * self.H))
+        self.n = n
+
+    def set_sequence_device(self, n_pairs, left_ptr, right_ptr, stride, frame_stride, keep=None):
+        self._keep = keep
+        self._check(self._L.vo_set_sequence_device(self._h, int(n_pairs), C.c_void_p(int(left_ptr)), C.c_void_p(int(right_ptr)),
+                                                   int(stride), int(frame_stride)))
+        self.n = int(n_pairs)
 
     # --- VOClass::computeDisparity
     def compute_disparity(self):

@@ -31,18 +31,20 @@ __device__ __forceinline__ int reflect101(int p, int len)
 }
 
 struct LevelArgs { int w, h, pitch, rows; unsigned img_off, der_off; };
-struct PyrArgs { int nlevels, border; LevelArgs lv[VO_MAX_LEVELS]; unsigned long long pyr_bytes, der_elems; };
+// img_per_b: image slots per batch entry, image (b, which) is slot b * img_per_b + which.  4 for independent pairs
+// (LT1, RT1, LT2, RT2); 2 for consecutive frames of a sequence, where (b, LT2) is the same image as (b + 1, LT1).
+struct PyrArgs { int nlevels, border, img_per_b; LevelArgs lv[VO_MAX_LEVELS]; unsigned long long pyr_bytes, der_elems; };
 
 __global__ __launch_bounds__(256) void level0_kernel(const uint8_t* i0, const uint8_t* i1, const uint8_t* i2, const uint8_t* i3,
                                                      size_t pitch, size_t fstride, PyrArgs pa, uint8_t* __restrict__ pyr)
 {
     const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y;
-    const int b = blockIdx.z >> 2, which = blockIdx.z & 3;
+    const int b = blockIdx.z / pa.img_per_b, which = blockIdx.z % pa.img_per_b;
     const LevelArgs L = pa.lv[0];
     if (px >= L.pitch) return;
     const uint8_t* src = (which == 0 ? i0 : which == 1 ? i1 : which == 2 ? i2 : i3) + (size_t)b * fstride;
     int x = reflect101(min(px, L.w + 2 * pa.border - 1) - pa.border, L.w), y = reflect101(py - pa.border, L.h);
-    pyr[((size_t)b * 4 + which) * pa.pyr_bytes + L.img_off + (size_t)py * L.pitch + px] = src[(size_t)y * pitch + x];
+    pyr[(size_t)blockIdx.z * pa.pyr_bytes + L.img_off + (size_t)py * L.pitch + px] = src[(size_t)y * pitch + x];
 }
 
 constexpr int PD_TX = 32, PD_TY = 8;
@@ -225,9 +227,9 @@ __global__ __launch_bounds__(256) void lk_row_kernel(LkArgs a, const uint8_t* __
     const float FLT_SCALE = 1.f / (float)(1 << 20);
 
     for (int leg = 0; leg < 4; leg++) {
-        const uint8_t* Ibase = pyr + ((size_t)b * 4 + leg_prev[leg]) * a.pa.pyr_bytes;
-        const uint8_t* Jbase = pyr + ((size_t)b * 4 + leg_next[leg]) * a.pa.pyr_bytes;
-        const int16_t* Dbase = der + ((size_t)b * 4 + leg_prev[leg]) * a.pa.der_elems;
+        const uint8_t* Ibase = pyr + ((size_t)b * a.pa.img_per_b + leg_prev[leg]) * a.pa.pyr_bytes;
+        const uint8_t* Jbase = pyr + ((size_t)b * a.pa.img_per_b + leg_next[leg]) * a.pa.pyr_bytes;
+        const int16_t* Dbase = der + ((size_t)b * a.pa.img_per_b + leg_prev[leg]) * a.pa.der_elems;
         float nx = 0.f, ny = 0.f;
         int status = 1;
         for (int level = nl; level >= 0; level--) {
@@ -421,7 +423,7 @@ static PyrArgs make_pyr_args(const vo_ctx* c)
 {
     PyrArgs pa;
     memset(&pa, 0, sizeof(pa));
-    pa.nlevels = c->nlevels; pa.border = c->border; pa.pyr_bytes = c->pyr_bytes; pa.der_elems = c->der_elems;
+    pa.nlevels = c->nlevels; pa.border = c->border; pa.img_per_b = c->seq_mode ? 2 : 4; pa.pyr_bytes = c->pyr_bytes; pa.der_elems = c->der_elems;
     for (int l = 0; l <= c->nlevels; l++) {
         pa.lv[l].w = c->lv[l].w; pa.lv[l].h = c->lv[l].h; pa.lv[l].pitch = c->lv[l].pitch; pa.lv[l].rows = c->lv[l].rows;
         pa.lv[l].img_off = (unsigned)c->lv[l].img_off; pa.lv[l].der_off = (unsigned)c->lv[l].der_off;
@@ -433,7 +435,7 @@ int launch_pyramids(vo_ctx* c)
 {
     StageTimer st_(c, VO_ST_PYRAMID);
     const PyrArgs pa = make_pyr_args(c);
-    const int nimg = 4 * c->n;
+    const int nimg = c->seq_mode ? 2 * (c->n + 1) : 4 * c->n;
     hipLaunchKernelGGL(level0_kernel, dim3((pa.lv[0].pitch + 255) / 256, pa.lv[0].rows, nimg), dim3(256), 0, c->stream,
                        c->img[0], c->img[1], c->img[2], c->img[3], c->pitch, c->fstride, pa, c->pyr);
     for (int l = 1; l <= c->nlevels; l++) {

@@ -228,7 +228,7 @@ extern "C" int vo_set_images(vo_ctx* c, int n, const uint8_t* lt1, const uint8_t
     }
     // the copies read pageable host memory: finish them before the caller may reuse its buffers
     VO_HIP(c, hipStreamSynchronize(c->stream));
-    c->pitch = c->own_pitch; c->fstride = c->own_fstride; c->n = n;
+    c->pitch = c->own_pitch; c->fstride = c->own_fstride; c->n = n; c->seq_mode = false;
     invalidate(c);
     return VO_OK;
 }
@@ -240,7 +240,41 @@ extern "C" int vo_set_images_device(vo_ctx* c, int n, const uint8_t* lt1, const 
     int rc = check_images(c, n, lt1, rt1, lt2, rt2, stride, frame_stride);
     if (rc) return rc;
     c->img[0] = lt1; c->img[1] = rt1; c->img[2] = lt2; c->img[3] = rt2;
-    c->pitch = stride; c->fstride = frame_stride; c->n = n;
+    c->pitch = stride; c->fstride = frame_stride; c->n = n; c->seq_mode = false;
+    invalidate(c);
+    return VO_OK;
+}
+
+extern "C" int vo_set_sequence(vo_ctx* c, int n_pairs, const uint8_t* left, const uint8_t* right, size_t stride, size_t frame_stride)
+{
+    CHECK_CTX(c);
+    int rc = check_images(c, n_pairs, left, right, left, right, stride, frame_stride);
+    if (rc) return rc;
+    if (frame_stride < stride * c->H) return vo_fail(c, VO_ERR_BAD_ARG, "stride smaller than the frame");
+    VO_HIP(c, hipSetDevice(c->device));
+    const uint8_t* src[2] = {left, right};
+    const size_t B = c->p.max_batch;
+    for (int i = 0; i < 2; i++) {
+        uint8_t* dst = c->img_own + (size_t)i * (B + 1) * c->own_fstride; // 2 (B + 1) frames fit the 4 B frames of the pair layout
+        for (int f = 0; f <= n_pairs; f++)
+            VO_HIP(c, hipMemcpy2DAsync(dst + (size_t)f * c->own_fstride, c->own_pitch, src[i] + (size_t)f * frame_stride, stride, c->W, c->H,
+                                       hipMemcpyHostToDevice, c->stream));
+        c->img[i] = dst; c->img[i + 2] = dst + c->own_fstride;
+    }
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    c->pitch = c->own_pitch; c->fstride = c->own_fstride; c->n = n_pairs; c->seq_mode = true;
+    invalidate(c);
+    return VO_OK;
+}
+
+extern "C" int vo_set_sequence_device(vo_ctx* c, int n_pairs, const uint8_t* left, const uint8_t* right, size_t stride, size_t frame_stride)
+{
+    CHECK_CTX(c);
+    int rc = check_images(c, n_pairs, left, right, left, right, stride, frame_stride);
+    if (rc) return rc;
+    if (frame_stride < stride * c->H) return vo_fail(c, VO_ERR_BAD_ARG, "stride smaller than the frame");
+    c->img[0] = left; c->img[1] = right; c->img[2] = left + frame_stride; c->img[3] = right + frame_stride;
+    c->pitch = stride; c->fstride = frame_stride; c->n = n_pairs; c->seq_mode = true;
     invalidate(c);
     return VO_OK;
 }
@@ -628,8 +662,8 @@ extern "C" int vo_read_tap(vo_ctx* c, int tap, int b, int arg0, int arg1, void* 
         const size_t esz = tap == VO_TAP_PYR_LEVEL ? 1 : 4;
         if (bytes != (size_t)L.w * L.h * esz) return vo_fail(c, VO_ERR_BAD_ARG, "tap size");
         const char* base = tap == VO_TAP_PYR_LEVEL
-            ? (const char*)(c->pyr + ((size_t)b * 4 + arg0) * c->pyr_bytes + L.img_off)
-            : (const char*)(c->der + ((size_t)b * 4 + arg0) * c->der_elems + L.der_off);
+            ? (const char*)(c->pyr + ((size_t)b * (c->seq_mode ? 2 : 4) + arg0) * c->pyr_bytes + L.img_off)
+            : (const char*)(c->der + ((size_t)b * (c->seq_mode ? 2 : 4) + arg0) * c->der_elems + L.der_off);
         const char* src = base + ((size_t)c->border * L.pitch + c->border) * esz;
         VO_HIP(c, hipMemcpy2DAsync(out, (size_t)L.w * esz, src, (size_t)L.pitch * esz, (size_t)L.w * esz, L.h, hipMemcpyDeviceToHost, c->stream));
         VO_HIP(c, hipStreamSynchronize(c->stream));

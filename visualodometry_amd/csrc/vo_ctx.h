@@ -47,6 +47,9 @@ struct vo_ctx {
     const uint8_t* img[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t pitch = 0, fstride = 0;
     uint8_t* img_own = nullptr; size_t own_pitch = 0, own_fstride = 0;
+    // consecutive frames of one sequence: pair b is (frame b, frame b + 1), so img[2] = img[0] + fstride and
+    // img[3] = img[1] + fstride, and the pyramids are built once per frame ([n + 1][2]) instead of [n][4]
+    bool seq_mode = false;
 
     // ---- SGBM ----
     uint8_t* pre = nullptr;      // prefiltered rows: [n][2 images][H][Wp] x 8 bytes (g,g0,g1,r,r0,r1,0,0)

@@ -52,11 +52,8 @@ def run_sequence(ctx, frames, batch=None):
     Rts, infos = [], []
     for s in range(0, n - 1, batch):
         e = min(s + batch, n - 1)
-        lt1 = np.stack([frames[i][0] for i in range(s, e)])
-        rt1 = np.stack([frames[i][1] for i in range(s, e)])
-        lt2 = np.stack([frames[i + 1][0] for i in range(s, e)])
-        rt2 = np.stack([frames[i + 1][1] for i in range(s, e)])
-        ctx.set_images(lt1, rt1, lt2, rt2)
+        # frames s..e: pair i is (frame i, frame i + 1); each frame is uploaded and pyramided once
+        ctx.set_sequence(np.stack([frames[i][0] for i in range(s, e + 1)]), np.stack([frames[i][1] for i in range(s, e + 1)]))
         Rt, info = ctx.step()
         Rts.extend(Rt)
         infos.extend(info)
