@@ -463,6 +463,192 @@ __global__ __launch_bounds__(256) void hpath_kernel(const int16_t* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------- horizontal paths, two-pass form
+// The left-to-right path L_lr is needed again when the right-to-left pass forms S = L_rl + (L_lr + L_top), but a row of it
+// (width1 x D x 2 bytes) is far too large to keep on chip and storing it costs a volume write plus a volume read.
+// Instead:
+//   hpath_ckpt_kernel    runs L_lr over the row once and keeps only its state (L_lr[D], min) at every HP_SEG-th column;
+//   hpath_resolve_kernel walks the segments right to left; per segment it replays L_lr from the checkpoint into registers
+//                        (HP_SEG columns x 2NP cells per lane), then runs L_rl back over the same columns with S, the
+//                        winner and its neighbours.  Lane u of a row keeps the result of the segment's column u, so the
+//                        sub-pixel fit and the store happen once per segment with all lanes busy.
+// Traffic per cost cell: C twice and L_top once (6 bytes) instead of 10; only image rows that produce output are
+// walked (the warm-up rows of a stripe matter to the vertical path alone).
+
+// stripe row of image row y
+__device__ __forceinline__ int stripe_row_of(const StripeInfo& si, int stripe_sz, int y)
+{
+    const int s = min(y / stripe_sz, 3);
+    return si.off[s] + (y - si.y0[s]);
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void hpath_ckpt_kernel(const int16_t* __restrict__ cost, int width1, int D, int H, int srows, StripeInfo si,
+                                                         int stripe_sz, int P1, int P2, int nseg, int* __restrict__ ckpt)
+{
+    constexpr int HP_SEG = vo_hpath_seg(NP);
+    const int lane16 = threadIdx.x & 15;
+    const int y = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int b = blockIdx.y;
+    const bool active = y < H;
+    const int yy = active ? y : H - 1;
+    const int sr = stripe_row_of(si, stripe_sz, yy);
+    const int16_t* Cp = cost + (((size_t)b * srows + sr) * width1) * D + lane16 * (2 * NP);
+    int* ck = ckpt + (((size_t)b * H + yy) * nseg * 16 + lane16) * (NP + 1);
+    const int inf_pk = (32767 - P1) * 0x10001;
+    v2s Lp[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) Lp[k] = splat(0);
+    int m = 0;
+    constexpr int U = 8;
+    v2s cur[U][NP], nxt[U][NP];
+    auto load_group = [&](int x0, v2s (&g)[U][NP]) {
+#pragma unroll
+        for (int u = 0; u < U; u++) load_pk<NP>(Cp + (size_t)min(x0 + u, width1 - 1) * D, g[u]);
+    };
+    load_group(0, cur);
+    for (int x0 = 0; x0 < width1; x0 += U) {
+        if (x0 + U < width1) load_group(x0 + U, nxt);
+        if ((x0 % HP_SEG) == 0 && active) { // state before column x0
+            int* q = ck + (size_t)(x0 / HP_SEG) * 16 * (NP + 1);
+#pragma unroll
+            for (int k = 0; k < NP; k++) q[k] = as_int(Lp[k]);
+            q[NP] = m;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (x0 + u < width1) m = path_step<NP>(cur[u], Lp, m, P1, P2, inf_pk);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int k = 0; k < NP; k++) cur[u][k] = nxt[u][k];
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void hpath_resolve_kernel(const int16_t* __restrict__ cost, const int16_t* __restrict__ ltop, int width1,
+                                                            int D, int W, int H, int srows, StripeInfo si, int stripe_sz, int P1, int P2,
+                                                            int tie_lanes, int nseg, const int* __restrict__ ckpt, int32_t* __restrict__ wta)
+{
+    constexpr int HP_SEG = vo_hpath_seg(NP);
+    const int lane16 = threadIdx.x & 15;
+    const int y = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int b = blockIdx.y;
+    const bool active = y < H;
+    const int yy = active ? y : H - 1;
+    const int sr = stripe_row_of(si, stripe_sz, yy);
+    const size_t base = (((size_t)b * srows + sr) * width1) * D + lane16 * (2 * NP);
+    const int16_t* Cp = cost + base;
+    const int16_t* Tp = ltop + base;
+    const int* ck = ckpt + (((size_t)b * H + yy) * nseg * 16 + lane16) * (NP + 1);
+    int32_t* out = wta + ((size_t)b * srows + sr) * W + (W - width1);
+    const int inf_pk = (32767 - P1) * 0x10001;
+    const int dbase = lane16 * (2 * NP);
+
+    v2s LpR[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) LpR[k] = splat(0);
+    int mR = 0;
+
+    v2s Cc[HP_SEG][NP], Cn[HP_SEG][NP], Tt[HP_SEG][NP], Lrec[HP_SEG][NP];
+    int ckc[NP + 1], ckn[NP + 1];
+    auto load_seg = [&](const int16_t* p, int s, v2s (&g)[HP_SEG][NP]) {
+#pragma unroll
+        for (int u = 0; u < HP_SEG; u++) load_pk<NP>(p + (size_t)min(s * HP_SEG + u, width1 - 1) * D, g[u]);
+    };
+    auto load_ck = [&](int s, int (&c)[NP + 1]) {
+        const int* q = ck + (size_t)s * 16 * (NP + 1);
+#pragma unroll
+        for (int k = 0; k <= NP; k++) c[k] = q[k];
+    };
+    load_seg(Cp, nseg - 1, Cc);
+    load_ck(nseg - 1, ckc);
+    for (int s = nseg - 1; s >= 0; s--) {
+        const int x0 = s * HP_SEG;
+        const int cols = min(HP_SEG, width1 - x0);
+        load_seg(Tp, s, Tt);
+        // replay L_lr over the segment
+        v2s Lp[NP];
+#pragma unroll
+        for (int k = 0; k < NP; k++) Lp[k] = as_v2s(ckc[k]);
+        int m = ckc[NP];
+#pragma unroll
+        for (int u = 0; u < HP_SEG; u++) {
+            if (u < cols) m = path_step<NP>(Cc[u], Lp, m, P1, P2, inf_pk);
+#pragma unroll
+            for (int k = 0; k < NP; k++) Lrec[u][k] = Lp[k];
+        }
+        if (s > 0) { load_seg(Cp, s - 1, Cn); load_ck(s - 1, ckn); }
+        // L_rl, S and the winner, right to left; lane u keeps column u's result
+        int kminS = 0, kbest = 0, knb = 0;
+#pragma unroll
+        for (int u = HP_SEG - 1; u >= 0; u--) {
+            if (u < cols) { // uniform
+                mR = path_step<NP>(Cc[u], LpR, mR, P1, P2, inf_pk);
+                v2s S[NP];
+#pragma unroll
+                for (int k = 0; k < NP; k++) S[k] = __builtin_elementwise_add_sat(LpR[k], Lrec[u][k] + Tt[u][k]);
+                v2s mm = S[0];
+#pragma unroll
+                for (int k = 1; k < NP; k++) mm = vmin(mm, S[k]);
+                const int minS = row_min(min((int)mm.x, (int)mm.y));
+                int first = 1 << 20, cnt = 0;
+#pragma unroll
+                for (int k = NP - 1; k >= 0; k--) {
+                    if ((int)S[k].y == minS) { first = dbase + 2 * k + 1; cnt++; }
+                    if ((int)S[k].x == minS) { first = dbase + 2 * k; cnt++; }
+                }
+                int best = row_min(first);
+                if (tie_lanes > 0) {
+                    int total = row_add(cnt);
+                    if (__any(total > 1)) {
+                        // vectorised-loop rule: per SIMD lane class the last tie, then the smallest of those
+                        int bb = 1 << 20;
+                        for (int c = 0; c < tie_lanes; c++) {
+                            int last = -1;
+#pragma unroll
+                            for (int k = 0; k < NP; k++) {
+                                int d0 = dbase + 2 * k;
+                                if ((int)S[k].x == minS && (d0 % tie_lanes) == c) last = max(last, d0);
+                                if ((int)S[k].y == minS && ((d0 + 1) % tie_lanes) == c) last = max(last, d0 + 1);
+                            }
+                            last = row_max(last);
+                            if (last >= 0) bb = min(bb, last);
+                        }
+                        best = bb;
+                    }
+                }
+                int nb = 0; // neighbours of the winner for the parabola fit
+#pragma unroll
+                for (int k = 0; k < NP; k++) {
+                    int d0 = dbase + 2 * k;
+                    if (d0 == best - 1) nb |= (int)S[k].x & 0xffff;
+                    if (d0 + 1 == best - 1) nb |= (int)S[k].y & 0xffff;
+                    if (d0 == best + 1) nb |= ((int)S[k].x & 0xffff) << 16;
+                    if (d0 + 1 == best + 1) nb |= ((int)S[k].y & 0xffff) << 16;
+                }
+                nb = row_or(nb);
+                if (lane16 == u) { kminS = minS; kbest = best; knb = nb; }
+            }
+        }
+        if (active && lane16 < cols) {
+            int d16 = kbest * 16;
+            if (kbest > 0 && kbest < D - 1) {
+                int sm = (short)(knb & 0xffff), sp = (short)(knb >> 16);
+                int denom2 = max(sm + sp - 2 * kminS, 1);
+                d16 += ((sm - sp) * 16 + denom2) / (denom2 * 2);
+            }
+            out[x0 + lane16] = (int)(((unsigned)kminS << 16) | ((unsigned)d16 & 0xffffu));
+        }
+#pragma unroll
+        for (int u = 0; u < HP_SEG; u++)
+#pragma unroll
+            for (int k = 0; k < NP; k++) Cc[u][k] = Cn[u][k];
+#pragma unroll
+        for (int k = 0; k <= NP; k++) ckc[k] = ckn[k];
+    }
+}
+
 // ---------------------------------------------------------------- right-view disparity + consistency check
 __global__ __launch_bounds__(256) void lrcheck_kernel(const int32_t* __restrict__ wta, int W, int H, int width1, int srows,
                                                       StripeInfo si, int stripe_sz, int disp12, int16_t* __restrict__ disp_pre)
@@ -567,6 +753,7 @@ int run_sgbm(vo_ctx* c)
         hipLaunchKernelGGL((cost_vpath_kernel<NP, 0>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
                            SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring);
     }
+#ifdef VO_HPATH_STORE_LLR
     { StageTimer st_(c, VO_ST_HPATH_FWD);
     hipLaunchKernelGGL((hpath_kernel<NP, false>), dim3((c->srows + 15) / 16, n), dim3(256), 0, c->stream, c->cost, c->agg, w1, D, W,
                        c->srows, c->P1, c->P2, c->p.wta_simd_lanes, c->wta);
@@ -575,6 +762,17 @@ int run_sgbm(vo_ctx* c)
     hipLaunchKernelGGL((hpath_kernel<NP, true>), dim3((c->srows + 15) / 16, n), dim3(256), 0, c->stream, c->cost, c->agg, w1, D, W,
                        c->srows, c->P1, c->P2, c->p.wta_simd_lanes, c->wta);
     }
+#else
+    const int nseg = vo_hpath_segments(c);
+    { StageTimer st_(c, VO_ST_HPATH_FWD);
+    hipLaunchKernelGGL((hpath_ckpt_kernel<NP>), dim3((H + 15) / 16, n), dim3(256), 0, c->stream, c->cost, w1, D, H, c->srows, si, c->stripe_sz,
+                       c->P1, c->P2, nseg, c->ckpt);
+    }
+    { StageTimer st_(c, VO_ST_HPATH_BWD);
+    hipLaunchKernelGGL((hpath_resolve_kernel<NP>), dim3((H + 15) / 16, n), dim3(256), 0, c->stream, c->cost, c->agg, w1, D, W, H, c->srows, si,
+                       c->stripe_sz, c->P1, c->P2, c->p.wta_simd_lanes, nseg, c->ckpt, c->wta);
+    }
+#endif
     { StageTimer st_(c, VO_ST_LRCHECK);
     hipLaunchKernelGGL(lrcheck_kernel, dim3(H, n), dim3(256), (size_t)W * 4, c->stream, c->wta, W, H, w1, c->srows, si, c->stripe_sz,
                        c->disp12, c->disp_pre);

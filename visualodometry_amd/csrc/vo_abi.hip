@@ -130,6 +130,7 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     CR(dalloc(&c->cost, B * c->srows * w1 * D));
     CR(dalloc(&c->agg, B * c->srows * w1 * D));
     CR(dalloc(&c->wta, B * c->srows * W));
+    CR(dalloc(&c->ckpt, B * H * (size_t)vo_hpath_segments(c) * 16 * (D / 32 + 1)));
     CR(dalloc(&c->disp_pre, B * H * W));
     CR(dalloc(&c->disp16, B * H * W));
     CR(dalloc(&c->disp32, B * H * W));
@@ -166,7 +167,7 @@ extern "C" void vo_destroy(vo_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->img_own, c->pre, c->ring, c->cost, c->agg, c->wta, c->disp_pre, c->disp16, c->disp32, c->depth, c->score,
+    void* bufs[] = {c->img_own, c->pre, c->ring, c->cost, c->agg, c->wta, c->ckpt, c->disp_pre, c->disp16, c->disp32, c->depth, c->score,
                     c->row_count, c->row_off, c->n_feat, c->feat, c->pyr, c->der, c->legs, c->leg_status, c->m1, c->m2, c->n_match,
                     c->obj, c->obj_img, c->n_obj, c->hyp, c->hyp_count, c->hyp_mask};
     for (void* b : bufs) if (b) (void)hipFree(b);

@@ -57,6 +57,7 @@ struct vo_ctx {
     int16_t* cost = nullptr;     // [n][srows][width1][D]
     int16_t* agg = nullptr;      // [n][srows][width1][D]  L_top, then L_top + L_lr
     int32_t* wta = nullptr;      // [n][srows][W] packed (minS << 16) | (d16 & 0xffff)
+    int* ckpt = nullptr;         // [n][H][segments][16 lanes][D / 32 + 1]: left-to-right path state at segment starts
     int16_t* disp_pre = nullptr; // [n][H][W]
     int16_t* disp16 = nullptr;   // [n][H][W]
     float* disp32 = nullptr;     // [n][H][W]
@@ -136,6 +137,11 @@ inline size_t vo_cost_tiles(const vo_ctx* c)
     const int tile_out = VO_COST_TILE_COLS - 2 * (c->p.block_size / 2);
     return (size_t)((c->width1 + tile_out - 1) / tile_out);
 }
+
+// horizontal paths: the left-to-right state is checkpointed every segment; a segment's columns live in registers,
+// so wide disparity ranges (more cells per lane) get shorter segments
+constexpr int vo_hpath_seg(int pairs_per_lane) { return pairs_per_lane <= 4 ? 16 : 8; }
+inline int vo_hpath_segments(const vo_ctx* c) { const int seg = vo_hpath_seg(c->D / 32); return (c->width1 + seg - 1) / seg; }
 
 // ---- launchers (each enqueues on c->stream, returns a vo_status) ----
 int launch_fast(vo_ctx* c);
