@@ -32,7 +32,9 @@ __device__ __forceinline__ v2s splat(int s) { v2s r; r.x = (short)s; r.y = (shor
 __device__ __forceinline__ v2s vmin(v2s a, v2s b) { return __builtin_elementwise_min(a, b); }
 
 // reductions over the 16 lanes of a DPP row; every lane ends with the result
-#define DPP_STEP(v, ctrl) __builtin_amdgcn_update_dpp((v), (v), (ctrl), 0xF, 0xF, false)
+// (every lane of these four patterns has a valid source lane; "bound_ctrl with a zero old value" is merely the operand
+// form that lets the DPP move fold into the min / max / add / or itself)
+#define DPP_STEP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
 __device__ __forceinline__ int row_min(int v)
 {
     v = min(v, DPP_STEP(v, 0xB1)); v = min(v, DPP_STEP(v, 0x4E));
@@ -574,9 +576,9 @@ __global__ __launch_bounds__(256) void hpath_resolve_kernel(const int16_t* __res
         int m = ckc[NP];
 #pragma unroll
         for (int u = 0; u < HP_SEG; u++) {
-            if (u < cols) m = path_step<NP>(Cc[u], Lp, m, P1, P2, inf_pk);
 #pragma unroll
-            for (int k = 0; k < NP; k++) Lrec[u][k] = Lp[k];
+            for (int k = 0; k < NP; k++) Lrec[u][k] = u == 0 ? Lp[k] : Lrec[u - 1][k];
+            if (u < cols) m = path_step<NP>(Cc[u], Lrec[u], m, P1, P2, inf_pk); // steps in place on the column's own registers
         }
         if (s > 0) { load_seg(Cp, s - 1, Cn); load_ck(s - 1, ckn); }
         // L_rl, S and the winner, right to left; lane u keeps column u's result
