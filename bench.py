@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0)
-    ap.add_argument("--inflight", type=int, default=2, help="contexts taking turns (overlaps host PnP with GPU work)")
+    ap.add_argument("--inflight", type=int, default=3, help="contexts taking turns (overlaps host PnP with GPU work)")
     ap.add_argument("--mode", default="pairs", choices=["pairs", "sequence"],
                     help="pairs: B independent frame pairs, 4 pyramids each (what the reference rebuilds per step); "
                          "sequence: B + 1 consecutive frames, every frame pyramided once")

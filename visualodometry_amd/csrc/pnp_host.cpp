@@ -6,6 +6,10 @@
 #include <atomic>
 #include <functional>
 #include <chrono>
+#include <mutex>
+#include <condition_variable>
+#include <stdio.h>
+#include <stdlib.h>
 
 namespace pnp_host {
 
@@ -414,12 +418,15 @@ int iterative(const double* obj, const double* img, int n, const double K[9], do
             l[8] = x * M[0]; l[9] = x * M[1]; l[10] = x * M[2]; l[11] = x;
             l[20] = y * M[0]; l[21] = y * M[1]; l[22] = y * M[2]; l[23] = y;
         }
+        // L^T L in one pass over the rows: every entry is still the sum of its products in row order, so the result
+        // is the same as 144 separate dot products (and symmetric entries are the same products)
         double LL[144];
-        for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) {
-            double s = 0;
-            for (int i = 0; i < 2 * n; i++) s += L[(size_t)i * 12 + r] * L[(size_t)i * 12 + c];
-            LL[r * 12 + c] = s;
+        for (int k = 0; k < 144; k++) LL[k] = 0;
+        for (int i = 0; i < 2 * n; i++) {
+            const double* l = &L[(size_t)i * 12];
+            for (int r = 0; r < 12; r++) for (int c = r; c < 12; c++) LL[r * 12 + c] += l[r] * l[c];
         }
+        for (int r = 0; r < 12; r++) for (int c = 0; c < r; c++) LL[r * 12 + c] = LL[c * 12 + r];
         double LW[12], LU[144], LV[144];
         sla::svd(LL, 12, 12, LW, LU, LV, ws);
         double P[12];
@@ -478,16 +485,18 @@ int iterative(const double* obj, const double* img, int n, const double K[9], do
     };
     for (;;) {
         evaluate(param, true);
-        for (int r = 0; r < 6; r++) {
-            for (int c = r; c < 6; c++) {
-                double s = 0;
-                for (int i = 0; i < m; i++) s += J[(size_t)i * 6 + r] * J[(size_t)i * 6 + c];
-                JtJ[r * 6 + c] = JtJ[c * 6 + r] = s;
+        // one pass over J; each accumulator adds its products in row order, like a dot product per entry
+        for (int k = 0; k < 36; k++) JtJ[k] = 0;
+        for (int k = 0; k < 6; k++) JtErr[k] = 0;
+        for (int i = 0; i < m; i++) {
+            const double* j = &J[(size_t)i * 6];
+            const double e = err[i];
+            for (int r = 0; r < 6; r++) {
+                for (int c = r; c < 6; c++) JtJ[r * 6 + c] += j[r] * j[c];
+                JtErr[r] += j[r] * e;
             }
-            double s = 0;
-            for (int i = 0; i < m; i++) s += J[(size_t)i * 6 + r] * err[i];
-            JtErr[r] = s;
         }
+        for (int r = 0; r < 6; r++) for (int c = 0; c < r; c++) JtJ[r * 6 + c] = JtJ[c * 6 + r];
         memcpy(prev, param, sizeof(param));
         if (iters == 0) prevErrNorm = err_norm();
         lm_step();
@@ -512,16 +521,59 @@ int iterative(const double* obj, const double* img, int n, const double K[9], do
 // ------------------------------------------------------------------ batched RANSAC over GPU-scored hypotheses
 namespace {
 
-void parallel_for(int count, int threads, const std::function<void(int)>& fn)
+// Worker threads that live as long as their context: a batch needs two or three short parallel sections, and starting
+// threads for each of them costs more than the sections themselves.
+class Pool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(int)>* fn = nullptr;
+    int count = 0, active = 0;
+    unsigned long long gen = 0;
+    std::atomic<int> next{0};
+    bool stop = false;
+
+    void loop()
+    {
+        unsigned long long seen = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_work.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            const std::function<void(int)>* f = fn;
+            const int cnt = count;
+            lk.unlock();
+            for (int i = next.fetch_add(1); i < cnt; i = next.fetch_add(1)) (*f)(i);
+            lk.lock();
+            if (--active == 0) cv_done.notify_one();
+        }
+    }
+
+public:
+    explicit Pool(int workers) { for (int t = 0; t < workers; t++) th.emplace_back([this] { loop(); }); }
+    ~Pool()
+    {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_work.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void run(int cnt, const std::function<void(int)>& f)
+    {
+        if (th.empty() || cnt <= 1) { for (int i = 0; i < cnt; i++) f(i); return; }
+        { std::lock_guard<std::mutex> lk(mu); fn = &f; count = cnt; next.store(0); active = (int)th.size(); gen++; }
+        cv_work.notify_all();
+        for (int i = next.fetch_add(1); i < cnt; i = next.fetch_add(1)) f(i); // the caller works too
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return active == 0; });
+    }
+};
+
+void parallel_for(vo_ctx* c, int count, int threads, const std::function<void(int)>& fn)
 {
-    threads = std::max(1, std::min(threads, count));
-    if (threads == 1) { for (int i = 0; i < count; i++) fn(i); return; }
-    std::atomic<int> next(0);
-    std::vector<std::thread> pool;
-    auto work = [&]() { for (int i = next.fetch_add(1); i < count; i = next.fetch_add(1)) fn(i); };
-    for (int t = 1; t < threads; t++) pool.emplace_back(work);
-    work();
-    for (auto& th : pool) th.join();
+    if (threads <= 1 || count <= 1) { for (int i = 0; i < count; i++) fn(i); return; }
+    if (!c->host_pool) c->host_pool = new Pool(threads - 1);
+    static_cast<Pool*>(c->host_pool)->run(count, fn);
 }
 
 struct FrameRansac {
@@ -540,7 +592,7 @@ struct FrameRansac {
 
 } // namespace
 
-int estimate_motion_batch(vo_ctx* c, double* Rt_out, vo_frame_info* info)
+static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info)
 {
     const int n = c->n, chunk = c->p.ransac_chunk;
     const size_t F = c->p.max_features;
@@ -588,7 +640,7 @@ int estimate_motion_batch(vo_ctx* c, double* Rt_out, vo_frame_info* info)
         for (int b = 0; b < n; b++) any = any || (fr[b].active && fr[b].iter < fr[b].niters);
         if (!any) break;
         // minimal solver on the host: the next `chunk` subsets of every frame still iterating
-        parallel_for(n, threads, [&](int b) {
+        parallel_for(c, n, threads, [&](int b) {
             FrameRansac& f = fr[b];
             f.nh = 0; f.best_h = -1;
             if (!f.active || f.iter >= f.niters) return;
@@ -639,8 +691,9 @@ int estimate_motion_batch(vo_ctx* c, double* Rt_out, vo_frame_info* info)
     }
 
     // final solve on the inliers, Rodrigues, Rt
+    const auto host1 = std::chrono::steady_clock::now();
     std::vector<vo_frame_info> li(n);
-    parallel_for(n, threads, [&](int b) {
+    parallel_for(c, n, threads, [&](int b) {
         FrameRansac& f = fr[b];
         vo_frame_info& o = li[b];
         memset(&o, 0, sizeof(o));
@@ -672,12 +725,33 @@ int estimate_motion_batch(vo_ctx* c, double* Rt_out, vo_frame_info* info)
         Rt[12] = Rt[13] = Rt[14] = 0; Rt[15] = 1;
     });
     if (info) memcpy(info, li.data(), (size_t)n * sizeof(vo_frame_info));
+    if (getenv("VO_PNP_TRACE")) {
+        const auto host2 = std::chrono::steady_clock::now();
+        int it = 0; for (int b = 0; b < n; b++) it = std::max(it, fr[b].iter);
+        fprintf(stderr, "[pnp] rounds part %.3f ms (max iters %d), refine part %.3f ms, threads %d\n",
+                std::chrono::duration<double, std::milli>(host1 - host0).count(), it,
+                std::chrono::duration<double, std::milli>(host2 - host1).count(), threads);
+    }
     if (c->timing) {
         c->stage_ms[VO_ST_PNP_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host0).count();
         c->stage_calls[VO_ST_PNP_HOST]++;
     }
     if (status != VO_OK) return vo_fail(c, status, "a frame of the batch has fewer than 5 3D-2D correspondences");
     return VO_OK;
+}
+
+void destroy_pool(void* pool) { delete static_cast<Pool*>(pool); }
+
+// The RANSAC rounds are short host <-> GPU round trips (a few small copies and one scoring kernel each).  They run on
+// the context's high-priority stream so that they do not queue behind the bulk kernels other contexts have in flight.
+int estimate_motion_batch(vo_ctx* c, double* Rt_out, vo_frame_info* info)
+{
+    hipStream_t bulk = c->stream;
+    VO_HIP(c, hipStreamSynchronize(bulk));
+    if (c->stream_hi) c->stream = c->stream_hi;
+    const int rc = estimate_motion_rounds(c, Rt_out, info);
+    c->stream = bulk;
+    return rc;
 }
 
 } // namespace pnp_host

@@ -122,6 +122,11 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
 #define CR(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { vo_fail(nullptr, VO_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); vo_destroy(c); return VO_ERR_HIP; } } while (0)
     CR(hipSetDevice(device));
     CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        int least = 0, greatest = 0;
+        CR(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        CR(hipStreamCreateWithPriority(&c->stream_hi, hipStreamNonBlocking, greatest));
+    }
     const size_t B = c->p.max_batch, W = c->W, H = c->H, D = c->D, w1 = c->width1, F = c->p.max_features;
     c->own_pitch = (W + 63) & ~(size_t)63; c->own_fstride = c->own_pitch * H;
     CR(dalloc(&c->img_own, 4 * B * c->own_fstride));
@@ -173,8 +178,10 @@ extern "C" void vo_destroy(vo_ctx* c)
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
+    if (c->host_pool) pnp_host::destroy_pool(c->host_pool);
     if (c->step_done) (void)hipEventDestroy(c->step_done);
     for (int i = 0; i < VO_NUM_STAGES; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
+    if (c->stream_hi) (void)hipStreamDestroy(c->stream_hi);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

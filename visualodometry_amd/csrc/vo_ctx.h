@@ -25,6 +25,7 @@ struct vo_ctx {
     vo_params p;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_hi = nullptr; // highest priority: the short scoring round trips of the pose solver
     std::string err;
 
     // derived
@@ -102,6 +103,7 @@ struct vo_ctx {
     // pinned host staging
     void* h_stage = nullptr; size_t h_stage_bytes = 0;
     int* h_counts = nullptr; // pinned: [3][max_batch] feature / match / object-point counts of the pending step
+    void* host_pool = nullptr; // worker threads of the host-side solvers (pnp_host.cpp), created on first use
 
     // optional per-stage timing with HIP events on the context's stream
     bool timing = false;
