@@ -56,12 +56,15 @@ def kernel_bytes(W, H, D, srows, nframes):
     vol_s = srows * w1 * D * 2      # one per-stripe-row s16 volume (cost, path sums)
     P = W * H
     pyr = pyramid_pixels(W, H)
+    vol_h = H * w1 * D * 2          # the rows of a volume that produce output (no stripe warm-up rows)
+    seg = 16 if D // 32 <= 4 else 8
+    ckpt = H * (-(-w1 // seg)) * 16 * (D // 32 + 1) * 4
     per = {
         "sgbm_prefilter": 2 * P + 2 * P * 8,
-        "sgbm_vpath": 2 * P * 8 + 2 * vol_s,            # prefiltered rows in; C and L_top out
-        "sgbm_hpath_fwd": 2 * vol_s + vol_s,            # C, L_top in; L_lr + L_top out
-        "sgbm_hpath_bwd": 2 * vol_s + srows * W * 4,    # C, path sum in; packed winner out
-        "sgbm_lrcheck": srows * W * 4 + P * 2,
+        "sgbm_cost_vpath": 2 * P * 8 + 2 * vol_s,       # prefiltered rows in; C and L_top out
+        "sgbm_hpath_ckpt": vol_h + ckpt,                # C in; path state at segment starts out
+        "sgbm_hpath_resolve": 2 * vol_h + ckpt + H * W * 4,   # C, L_top, checkpoints in; packed winner out
+        "sgbm_lrcheck": H * W * 4 + P * 2,
         "sgbm_median": P * 2 + P * 2 + P * 4,
         "lk": 4 * (pyr + 4 * pyr + pyr),                # 4 legs x (previous image + its derivatives + next image)
     }
@@ -216,6 +219,14 @@ def main():
         for k, v in c.timing().items():
             a = timing.get(k, (0.0, 0))
             timing[k] = (a[0] + v[0], a[1] + v[1])
+    # outside the timed region: the same kernels with one batch in flight, i.e. without other batches' kernels
+    # sharing the GPU, which is the duration a kernel-level roofline should be read against
+    isolated = {}
+    if nctx > 1:
+        ctx.timing(reset=True)
+        for _ in range(3):
+            ctx.step()
+        isolated = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in ctx.timing().items()}
     if rank == 0:
         steps = args.steps
         fps = world * B * steps / dt
@@ -250,6 +261,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": stage_ms.get(dom, 0.0)},
         }
+        if isolated.get(dom, 0) > 0:
+            iso = kb[dom] / (isolated[dom] * 1e-3) / 1e9
+            out["roofline"].update({"avg_launch_ms_one_batch_in_flight": isolated[dom], "achieved_one_batch_in_flight": iso,
+                                    "frac_one_batch_in_flight": iso / HBM_PEAK_GBS})
+            out["config"]["stage_ms_one_batch_in_flight"] = {k: round(v, 4) for k, v in isolated.items()}
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(frames, seq, shape, args.cpu_pairs)
         print(json.dumps(out), flush=True)

@@ -14,8 +14,8 @@ import os
 import re
 import sys
 
-STAGE = {"prefilter_kernel": "sgbm_prefilter", "cost_vpath_kernel": "sgbm_vpath", "hpath_kernel<false>": "sgbm_hpath_fwd",
-         "hpath_kernel<true>": "sgbm_hpath_bwd", "lrcheck_kernel": "sgbm_lrcheck", "median_kernel": "sgbm_median",
+STAGE = {"prefilter_kernel": "sgbm_prefilter", "cost_vpath_kernel": "sgbm_cost_vpath", "hpath_ckpt_kernel": "sgbm_hpath_ckpt",
+         "hpath_resolve_kernel": "sgbm_hpath_resolve", "lrcheck_kernel": "sgbm_lrcheck", "median_kernel": "sgbm_median",
          "lk_row_kernel": "lk"}
 
 
