@@ -61,7 +61,7 @@ def kernel_bytes(W, H, D, srows, nframes):
     ckpt = H * (-(-w1 // seg)) * 16 * (D // 32 + 1) * 4
     per = {
         "sgbm_prefilter": 2 * P + 2 * P * 8,
-        "sgbm_cost_vpath": 2 * P * 8 + 2 * vol_s,       # prefiltered rows in; C and L_top out
+        "sgbm_cost_vpath": 2 * P * 8 + 2 * vol_h,       # prefiltered rows in; C and L_top out
         "sgbm_hpath_ckpt": vol_h + ckpt,                # C in; path state at segment starts out
         "sgbm_hpath_resolve": 2 * vol_h + ckpt + H * W * 4,   # C, L_top, checkpoints in; packed winner out
         "sgbm_lrcheck": H * W * 4 + P * 2,

@@ -58,10 +58,13 @@ def test_sgbm_bit_exact_small(small_seq):
     ctx.compute_disparity()
     op = oracle_params(p)
     want, want_pre = ob.sgbm(L, R, op, with_premedian=True)
-    # aggregated cost rows, one per stripe incl. the first row of a stripe and the last image row
-    for stripe, y in ((0, 0), (0, 5), (1, 24 - 9), (1, 30), (3, SMALL_H - 1)):
+    # aggregated cost rows, incl. the first output row of a stripe and the last image row (the warm-up rows of a
+    # stripe, here rows 15..23 of stripe 1, are computed but not kept: they only feed the vertical path)
+    for stripe, y in ((0, 0), (0, 5), (1, 24), (1, 30), (3, SMALL_H - 1)):
         c = ob.sgbm_cost_row(L, R, op, stripe, y)
         assert np.array_equal(ctx.tap(abi.TAP_COST_ROW, 0, stripe, y), c), (stripe, y)
+    with pytest.raises(abi.VoError):
+        ctx.tap(abi.TAP_COST_ROW, 0, 1, 24 - 9)
     assert np.array_equal(ctx.tap(abi.TAP_DISP_PREMEDIAN), want_pre)
     got = ctx.disparity16(0)
     assert np.array_equal(got, want)

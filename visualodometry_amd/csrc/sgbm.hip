@@ -164,7 +164,8 @@ __device__ __forceinline__ void store_pk(int16_t* __restrict__ p, const v2s (&v)
     for (int k = 0; k < NP; k++) q[k] = as_int(v[k]);
 }
 
-struct StripeInfo { int y0[4], rows[4], off[4]; };
+// y0: first source row a stripe walks (warm-up included), out0: first row whose results are used, off: stripe-row offset
+struct StripeInfo { int y0[4], rows[4], off[4], out0[4]; };
 
 // ---------------------------------------------------------------- pixel cost + 11x11 window + top-down path, fused
 // Block = VO_COST_THREADS threads in lane groups of 16; a lane group owns 4 adjacent tile columns (CV_COLS per block,
@@ -339,11 +340,13 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) m[j] = path_step<NP>(C[j], Lp[j], m[j], P1, P2, inf_pk); // four independent chains
+        if (y >= si.out0[stripe]) { // warm-up rows only feed the vertical path's state: nothing reads their C or L_top
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (ocol[j] != ~0u) {
-                store_pk<NP>(reinterpret_cast<int16_t*>(crow + ocol[j]), C[j]);
-                store_pk<NP>(reinterpret_cast<int16_t*>(arow + ocol[j]), Lp[j]);
+            for (int j = 0; j < 4; j++) {
+                if (ocol[j] != ~0u) {
+                    store_pk<NP>(reinterpret_cast<int16_t*>(crow + ocol[j]), C[j]);
+                    store_pk<NP>(reinterpret_cast<int16_t*>(arow + ocol[j]), Lp[j]);
+                }
             }
         }
         crow += rstride * sizeof(int16_t); arow += rstride * sizeof(int16_t);
@@ -731,7 +734,7 @@ int run_sgbm(vo_ctx* c)
     const int W = c->W, H = c->H, D = c->D, w1 = c->width1, n = c->n, SH2 = c->p.block_size / 2;
     const int Wp = W;
     StripeInfo si;
-    for (int s = 0; s < 4; s++) { si.y0[s] = c->stripe_y0[s]; si.rows[s] = c->stripe_rows[s]; si.off[s] = c->stripe_row_off[s]; }
+    for (int s = 0; s < 4; s++) { si.y0[s] = c->stripe_y0[s]; si.rows[s] = c->stripe_rows[s]; si.off[s] = c->stripe_row_off[s]; si.out0[s] = std::min(s * c->stripe_sz, H); }
     { StageTimer st_(c, VO_ST_PREFILTER);
     hipLaunchKernelGGL(prefilter_kernel, dim3((W + 255) / 256, H, 2 * n), dim3(256), 0, c->stream, c->img[0], c->img[1], c->pitch,
                        c->fstride, W, H, Wp, c->ftzero, reinterpret_cast<uint2*>(c->pre));

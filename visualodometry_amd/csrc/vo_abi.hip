@@ -660,7 +660,8 @@ extern "C" int vo_read_tap(vo_ctx* c, int tap, int b, int arg0, int arg1, void* 
     case VO_TAP_COST_ROW: {
         if (!c->have_disp || arg0 < 0 || arg0 > 3 || bytes != (size_t)c->width1 * c->D * 2) return vo_fail(c, VO_ERR_BAD_ARG, "tap size/state");
         int r = arg1 - c->stripe_y0[arg0];
-        if (r < 0 || r >= c->stripe_rows[arg0]) return vo_fail(c, VO_ERR_BAD_ARG, "row %d not in stripe %d", arg1, arg0);
+        if (r < 0 || r >= c->stripe_rows[arg0] || arg1 < arg0 * c->stripe_sz)
+            return vo_fail(c, VO_ERR_BAD_ARG, "row %d is not an output row of stripe %d (warm-up rows are not kept)", arg1, arg0);
         return d2h(c, out, c->cost + (((size_t)b * c->srows + c->stripe_row_off[arg0] + r) * c->width1) * c->D, bytes);
     }
     case VO_TAP_PYR_LEVEL:
