@@ -182,7 +182,7 @@ constexpr int CV_COLS = VO_COST_TILE_COLS;
 template <int NP, int SWC>
 __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2* __restrict__ pre, int W, int H, int Wp, int width1, int D, int SW2,
                                                          int srows, StripeInfo si, int P1, int P2, int16_t* __restrict__ cost,
-                                                         int16_t* __restrict__ agg, uint32_t* __restrict__ ring)
+                                                         int16_t* __restrict__ agg, uint32_t* __restrict__ ring, int lds_slots)
 {
     extern __shared__ int vt[]; // [2][CV_COLS][CS]: V of every tile column, dword (k, lane16) at k*16 + lane16
     constexpr int CS = 16 * NP + 4;
@@ -230,22 +230,42 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
     const int nslot = 2 * SW2 + 2;
     uint32_t* rg = ring + ((size_t)((b * 4 + stripe) * gridDim.x + blockIdx.x) * nslot) * (2 * NP * VO_COST_THREADS); // uniform
     const unsigned tid = threadIdx.x;
+    // the first lds_slots slots of the ring live in what LDS the tile leaves free (same layout; a thread only ever
+    // reads back its own dwords, so no barrier is involved); the others in global memory
+    unsigned* lring = reinterpret_cast<unsigned*>(vt + 2 * CV_COLS * CS);
     auto ring_put = [&](int slot, const v2s (&src)[4][NP]) {
-        uint32_t* q_ = rg + (size_t)slot * (2 * NP * VO_COST_THREADS);
+        unsigned pk[2 * NP];
 #pragma unroll
         for (int w = 0; w < 2 * NP; w++) { // cells (2w, 2w+1) of the thread's 4 x NP pairs, low bytes
             const int a0 = 2 * w, a1 = 2 * w + 1;
-            q_[w * VO_COST_THREADS + tid] = __builtin_amdgcn_perm((unsigned)as_int(src[a1 / NP][a1 % NP]), (unsigned)as_int(src[a0 / NP][a0 % NP]), 0x06040200u);
+            pk[w] = __builtin_amdgcn_perm((unsigned)as_int(src[a1 / NP][a1 % NP]), (unsigned)as_int(src[a0 / NP][a0 % NP]), 0x06040200u);
+        }
+        if (slot < lds_slots) {
+            unsigned* q_ = lring + slot * (2 * NP * VO_COST_THREADS);
+#pragma unroll
+            for (int w = 0; w < 2 * NP; w++) q_[w * VO_COST_THREADS + tid] = pk[w];
+        } else {
+            uint32_t* q_ = rg + (size_t)slot * (2 * NP * VO_COST_THREADS);
+#pragma unroll
+            for (int w = 0; w < 2 * NP; w++) q_[w * VO_COST_THREADS + tid] = pk[w];
         }
     };
     auto ring_get = [&](int slot, v2s (&dst)[4][NP]) {
-        const uint32_t* q_ = rg + (size_t)slot * (2 * NP * VO_COST_THREADS);
+        unsigned pk[2 * NP];
+        if (slot < lds_slots) {
+            const unsigned* q_ = lring + slot * (2 * NP * VO_COST_THREADS);
+#pragma unroll
+            for (int w = 0; w < 2 * NP; w++) pk[w] = q_[w * VO_COST_THREADS + tid];
+        } else {
+            const uint32_t* q_ = rg + (size_t)slot * (2 * NP * VO_COST_THREADS);
+#pragma unroll
+            for (int w = 0; w < 2 * NP; w++) pk[w] = q_[w * VO_COST_THREADS + tid];
+        }
 #pragma unroll
         for (int w = 0; w < 2 * NP; w++) {
-            const unsigned v = q_[w * VO_COST_THREADS + tid];
             const int a0 = 2 * w, a1 = 2 * w + 1;
-            dst[a0 / NP][a0 % NP] = as_v2s((int)__builtin_amdgcn_perm(0u, v, 0x0c010c00u));
-            dst[a1 / NP][a1 % NP] = as_v2s((int)__builtin_amdgcn_perm(0u, v, 0x0c030c02u));
+            dst[a0 / NP][a0 % NP] = as_v2s((int)__builtin_amdgcn_perm(0u, pk[w], 0x0c010c00u));
+            dst[a1 / NP][a1 % NP] = as_v2s((int)__builtin_amdgcn_perm(0u, pk[w], 0x0c030c02u));
         }
     };
 
@@ -742,7 +762,16 @@ int run_sgbm(vo_ctx* c)
     { StageTimer st_(c, VO_ST_VPATH);
     // the reference's window (11x11, Source/VOClass.cpp:242) gets the instantiation with a compile-time half window
     const int swc = SH2 == 5 ? 5 : 0;
-    const size_t lds = (size_t)2 * CV_COLS * (16 * NP + 4) * sizeof(int);
+    // LDS: the double-buffered tile, plus as many ring slots as fit a third of a CU's 160 KB (three blocks per CU
+    // is what the kernel's register use allows at 96 disparities)
+#ifndef VO_COST_LDS_BUDGET
+#define VO_COST_LDS_BUDGET (52 * 1024)
+#endif
+    const size_t tile_bytes = (size_t)2 * CV_COLS * (16 * NP + 4) * sizeof(int);
+    const size_t slot_bytes = (size_t)2 * NP * VO_COST_THREADS * sizeof(unsigned);
+    const int lds_slots = tile_bytes >= (size_t)VO_COST_LDS_BUDGET ? 0
+                        : (int)std::min<size_t>((VO_COST_LDS_BUDGET - tile_bytes) / slot_bytes, (size_t)(2 * SH2 + 2));
+    const size_t lds = tile_bytes + lds_slots * slot_bytes;
     const void* fn = swc ? reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 5>) : reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 0>);
     static bool lds_attr_set[2] = {false, false};
     if (lds > 48 * 1024 && !lds_attr_set[swc ? 1 : 0]) {
@@ -753,10 +782,10 @@ int run_sgbm(vo_ctx* c)
     const dim3 grid((w1 + tile_out - 1) / tile_out, 4, n), blk(VO_COST_THREADS);
     if (swc)
         hipLaunchKernelGGL((cost_vpath_kernel<NP, 5>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
-                           SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring);
+                           SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring, lds_slots);
     else
         hipLaunchKernelGGL((cost_vpath_kernel<NP, 0>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
-                           SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring);
+                           SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring, lds_slots);
     }
 #ifdef VO_HPATH_STORE_LLR
     { StageTimer st_(c, VO_ST_HPATH_FWD);
