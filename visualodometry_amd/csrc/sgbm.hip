@@ -12,9 +12,10 @@
 //                     marching down the stripe: pixel cost, running vertical window sum, horizontal window sum
 //                     through LDS -> aggregated cost C, top-down path L_top.  The minimum over D is a DPP row
 //                     reduction; d-1 / d+1 neighbours come from DPP row shifts.
-//  hpath_kernel     : 16 lanes per image row, 4 rows per wavefront, serial along x with register prefetch.
-//                     forward: L_lr, stores L_lr + L_top.  backward: L_rl, S = sum of the three paths,
-//                     winner-take-all with OpenCV's tie rule, sub-pixel fit, packed (minS, d16) per pixel.
+//  hpath_ckpt_kernel / hpath_resolve_kernel: 16 lanes per image row, 4 rows per wavefront, serial along x.
+//                     First pass: L_lr, keeping its state at segment starts.  Second pass, right to left: L_lr of a
+//                     segment replayed into registers, L_rl, S = sum of the three paths, winner-take-all with
+//                     OpenCV's tie rule, sub-pixel fit, packed (minS, d16) per pixel.
 //  lrcheck_kernel   : per image row, right-view disparity by an order-independent LDS atomic-min scatter
 //                     (smallest cost, then largest x), then the two-sided consistency test.
 //  median_kernel    : 3x3 median (replicated border) on the s16 map, plus the /16 float map.
@@ -374,121 +375,6 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
 }
 
 // ---------------------------------------------------------------- horizontal paths
-#ifndef VO_HP_U
-#define VO_HP_U 4
-#endif
-constexpr int HP_U = VO_HP_U; // steps per prefetch group
-
-template <int NP, bool BACKWARD>
-__global__ __launch_bounds__(256) void hpath_kernel(const int16_t* __restrict__ cost, int16_t* __restrict__ agg, int width1, int D,
-                                                    int W, int srows, int P1, int P2, int tie_lanes, int32_t* __restrict__ wta)
-{
-    const int lane16 = threadIdx.x & 15;
-    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int b = blockIdx.y;
-    const bool active = row < srows;
-    const int sr = active ? row : srows - 1;
-    const size_t base = (((size_t)b * srows + sr) * width1) * D + lane16 * (2 * NP);
-    const int16_t* Cp = cost + base;
-    int16_t* Ap = agg + base;
-    const int inf_pk = (32767 - P1) * 0x10001;
-    const int minX1 = W - width1;
-    const int dbase = lane16 * (2 * NP);
-
-    v2s Lp[NP];
-#pragma unroll
-    for (int k = 0; k < NP; k++) Lp[k] = splat(0);
-    int m = 0;
-
-    v2s cC[HP_U][NP], cA[HP_U][NP], nC[HP_U][NP], nA[HP_U][NP];
-    auto xof = [&](int step) { return BACKWARD ? width1 - 1 - step : step; };
-    auto load_group = [&](int step0, v2s (&gc)[HP_U][NP], v2s (&ga)[HP_U][NP]) {
-#pragma unroll
-        for (int u = 0; u < HP_U; u++) {
-            int x = xof(min(step0 + u, width1 - 1));
-            load_pk<NP>(Cp + (size_t)x * D, gc[u]);
-            load_pk<NP>(Ap + (size_t)x * D, ga[u]);
-        }
-    };
-    load_group(0, cC, cA);
-    for (int s0 = 0; s0 < width1; s0 += HP_U) {
-        if (s0 + HP_U < width1) load_group(s0 + HP_U, nC, nA);
-#pragma unroll
-        for (int u = 0; u < HP_U; u++) {
-            const int step = s0 + u;
-            if (step < width1) { // uniform
-                const int x = xof(step);
-                m = path_step<NP>(cC[u], Lp, m, P1, P2, inf_pk);
-                if (!BACKWARD) {
-                    v2s o[NP];
-#pragma unroll
-                    for (int k = 0; k < NP; k++) o[k] = Lp[k] + cA[u][k];
-                    if (active) store_pk<NP>(Ap + (size_t)x * D, o);
-                } else {
-                    v2s S[NP];
-#pragma unroll
-                    for (int k = 0; k < NP; k++) S[k] = __builtin_elementwise_add_sat(Lp[k], cA[u][k]);
-                    v2s mm = S[0];
-#pragma unroll
-                    for (int k = 1; k < NP; k++) mm = vmin(mm, S[k]);
-                    const int minS = row_min(min((int)mm.x, (int)mm.y));
-                    // ties: first and count
-                    int first = 1 << 20, cnt = 0;
-#pragma unroll
-                    for (int k = NP - 1; k >= 0; k--) {
-                        if ((int)S[k].y == minS) { first = dbase + 2 * k + 1; cnt++; }
-                        if ((int)S[k].x == minS) { first = dbase + 2 * k; cnt++; }
-                    }
-                    int best = row_min(first);
-                    if (tie_lanes > 0) {
-                        int total = row_add(cnt);
-                        if (__any(total > 1)) {
-                            // vectorised-loop rule: per SIMD lane class the last tie, then the smallest of those
-                            int bb = 1 << 20;
-                            for (int c = 0; c < tie_lanes; c++) {
-                                int last = -1;
-#pragma unroll
-                                for (int k = 0; k < NP; k++) {
-                                    int d0 = dbase + 2 * k;
-                                    if ((int)S[k].x == minS && (d0 % tie_lanes) == c) last = max(last, d0);
-                                    if ((int)S[k].y == minS && ((d0 + 1) % tie_lanes) == c) last = max(last, d0 + 1);
-                                }
-                                last = row_max(last);
-                                if (last >= 0) bb = min(bb, last);
-                            }
-                            best = bb;
-                        }
-                    }
-                    // neighbours of the winner for the parabola fit
-                    int nb = 0;
-#pragma unroll
-                    for (int k = 0; k < NP; k++) {
-                        int d0 = dbase + 2 * k;
-                        if (d0 == best - 1) nb |= (int)S[k].x & 0xffff;
-                        if (d0 + 1 == best - 1) nb |= (int)S[k].y & 0xffff;
-                        if (d0 == best + 1) nb |= ((int)S[k].x & 0xffff) << 16;
-                        if (d0 + 1 == best + 1) nb |= ((int)S[k].y & 0xffff) << 16;
-                    }
-                    nb = row_or(nb);
-                    int d16 = best * 16;
-                    if (best > 0 && best < D - 1) {
-                        int sm = (short)(nb & 0xffff), sp = (short)(nb >> 16);
-                        int denom2 = max(sm + sp - 2 * minS, 1);
-                        d16 += ((sm - sp) * 16 + denom2) / (denom2 * 2);
-                    }
-                    if (active && lane16 == 0)
-                        wta[((size_t)b * srows + sr) * W + (x + minX1)] = (int)(((unsigned)minS << 16) | ((unsigned)d16 & 0xffffu));
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < HP_U; u++)
-#pragma unroll
-            for (int k = 0; k < NP; k++) { cC[u][k] = nC[u][k]; cA[u][k] = nA[u][k]; }
-    }
-}
-
-// ---------------------------------------------------------------- horizontal paths, two-pass form
 // The left-to-right path L_lr is needed again when the right-to-left pass forms S = L_rl + (L_lr + L_top), but a row of it
 // (width1 x D x 2 bytes) is far too large to keep on chip and storing it costs a volume write plus a volume read.
 // Instead:
@@ -551,13 +437,13 @@ __global__ __launch_bounds__(256) void hpath_ckpt_kernel(const int16_t* __restri
 }
 
 template <int NP>
-__global__ __launch_bounds__(256) void hpath_resolve_kernel(const int16_t* __restrict__ cost, const int16_t* __restrict__ ltop, int width1,
+__global__ __launch_bounds__(64) void hpath_resolve_kernel(const int16_t* __restrict__ cost, const int16_t* __restrict__ ltop, int width1,
                                                             int D, int W, int H, int srows, StripeInfo si, int stripe_sz, int P1, int P2,
                                                             int tie_lanes, int nseg, const int* __restrict__ ckpt, int32_t* __restrict__ wta)
 {
     constexpr int HP_SEG = vo_hpath_seg(NP);
     const int lane16 = threadIdx.x & 15;
-    const int y = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 4); // one wavefront per block: four rows
     const int b = blockIdx.y;
     const bool active = y < H;
     const int yy = active ? y : H - 1;
@@ -568,7 +454,10 @@ __global__ __launch_bounds__(256) void hpath_resolve_kernel(const int16_t* __res
     const int* ck = ckpt + (((size_t)b * H + yy) * nseg * 16 + lane16) * (NP + 1);
     int32_t* out = wta + ((size_t)b * srows + sr) * W + (W - width1);
     const int inf_pk = (32767 - P1) * 0x10001;
-    const int dbase = lane16 * (2 * NP);
+    // exchange buffer of this row (16 lanes): [column of the segment][D / 2 packed sums], odd stride against bank conflicts
+    extern __shared__ int hp_lds[];
+    constexpr int STR = 16 * NP + 1;
+    int* trow = hp_lds + (threadIdx.x >> 4) * (HP_SEG * STR);
 
     v2s LpR[NP];
 #pragma unroll
@@ -577,10 +466,12 @@ __global__ __launch_bounds__(256) void hpath_resolve_kernel(const int16_t* __res
 
     v2s Cc[HP_SEG][NP], Cn[HP_SEG][NP], Tt[HP_SEG][NP], Lrec[HP_SEG][NP];
     int ckc[NP + 1], ckn[NP + 1];
-    auto load_seg = [&](const int16_t* p, int s, v2s (&g)[HP_SEG][NP]) {
+    auto load_cols = [&](const int16_t* p, int s, v2s (&g)[HP_SEG][NP], int u0, int u1) {
 #pragma unroll
-        for (int u = 0; u < HP_SEG; u++) load_pk<NP>(p + (size_t)min(s * HP_SEG + u, width1 - 1) * D, g[u]);
+        for (int u = 0; u < HP_SEG; u++)
+            if (u >= u0 && u < u1) load_pk<NP>(p + (size_t)min(s * HP_SEG + u, width1 - 1) * D, g[u]);
     };
+    auto load_seg = [&](const int16_t* p, int s, v2s (&g)[HP_SEG][NP]) { load_cols(p, s, g, 0, HP_SEG); };
     auto load_ck = [&](int s, int (&c)[NP + 1]) {
         const int* q = ck + (size_t)s * 16 * (NP + 1);
 #pragma unroll
@@ -603,68 +494,57 @@ __global__ __launch_bounds__(256) void hpath_resolve_kernel(const int16_t* __res
             for (int k = 0; k < NP; k++) Lrec[u][k] = u == 0 ? Lp[k] : Lrec[u - 1][k];
             if (u < cols) m = path_step<NP>(Cc[u], Lrec[u], m, P1, P2, inf_pk); // steps in place on the column's own registers
         }
-        if (s > 0) { load_seg(Cp, s - 1, Cn); load_ck(s - 1, ckn); }
-        // L_rl, S and the winner, right to left; lane u keeps column u's result
-        int kminS = 0, kbest = 0, knb = 0;
+        // next segment's C: the half the replay needs first now, the rest once this segment's columns have been consumed
+        if (s > 0) { load_cols(Cp, s - 1, Cn, 0, HP_SEG / 2); load_ck(s - 1, ckn); }
+        // L_rl and S, right to left.  S of the segment then goes through LDS so that lane u of the row owns all D sums of
+        // column u: the winner search runs once per column on one lane instead of 16 lanes co-operating on every column.
 #pragma unroll
         for (int u = HP_SEG - 1; u >= 0; u--) {
             if (u < cols) { // uniform
                 mR = path_step<NP>(Cc[u], LpR, mR, P1, P2, inf_pk);
-                v2s S[NP];
 #pragma unroll
-                for (int k = 0; k < NP; k++) S[k] = __builtin_elementwise_add_sat(LpR[k], Lrec[u][k] + Tt[u][k]);
-                v2s mm = S[0];
-#pragma unroll
-                for (int k = 1; k < NP; k++) mm = vmin(mm, S[k]);
-                const int minS = row_min(min((int)mm.x, (int)mm.y));
-                int first = 1 << 20, cnt = 0;
-#pragma unroll
-                for (int k = NP - 1; k >= 0; k--) {
-                    if ((int)S[k].y == minS) { first = dbase + 2 * k + 1; cnt++; }
-                    if ((int)S[k].x == minS) { first = dbase + 2 * k; cnt++; }
-                }
-                int best = row_min(first);
-                if (tie_lanes > 0) {
-                    int total = row_add(cnt);
-                    if (__any(total > 1)) {
-                        // vectorised-loop rule: per SIMD lane class the last tie, then the smallest of those
-                        int bb = 1 << 20;
-                        for (int c = 0; c < tie_lanes; c++) {
-                            int last = -1;
-#pragma unroll
-                            for (int k = 0; k < NP; k++) {
-                                int d0 = dbase + 2 * k;
-                                if ((int)S[k].x == minS && (d0 % tie_lanes) == c) last = max(last, d0);
-                                if ((int)S[k].y == minS && ((d0 + 1) % tie_lanes) == c) last = max(last, d0 + 1);
-                            }
-                            last = row_max(last);
-                            if (last >= 0) bb = min(bb, last);
-                        }
-                        best = bb;
-                    }
-                }
-                int nb = 0; // neighbours of the winner for the parabola fit
-#pragma unroll
-                for (int k = 0; k < NP; k++) {
-                    int d0 = dbase + 2 * k;
-                    if (d0 == best - 1) nb |= (int)S[k].x & 0xffff;
-                    if (d0 + 1 == best - 1) nb |= (int)S[k].y & 0xffff;
-                    if (d0 == best + 1) nb |= ((int)S[k].x & 0xffff) << 16;
-                    if (d0 + 1 == best + 1) nb |= ((int)S[k].y & 0xffff) << 16;
-                }
-                nb = row_or(nb);
-                if (lane16 == u) { kminS = minS; kbest = best; knb = nb; }
+                for (int k = 0; k < NP; k++) trow[u * STR + lane16 * NP + k] = as_int(__builtin_elementwise_add_sat(LpR[k], Lrec[u][k] + Tt[u][k]));
             }
         }
-        if (active && lane16 < cols) {
-            int d16 = kbest * 16;
-            if (kbest > 0 && kbest < D - 1) {
-                int sm = (short)(knb & 0xffff), sp = (short)(knb >> 16);
-                int denom2 = max(sm + sp - 2 * kminS, 1);
-                d16 += ((sm - sp) * 16 + denom2) / (denom2 * 2);
+        if (s > 0) load_cols(Cp, s - 1, Cn, HP_SEG / 2, HP_SEG);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // same-wavefront exchange: program order in the LDS queue is enough
+        {
+            const int* col = trow + min(lane16, HP_SEG - 1) * STR;
+            const int16_t* col16 = reinterpret_cast<const int16_t*>(col);
+            v2s T[16 * NP];
+#pragma unroll
+            for (int j = 0; j < 16 * NP; j++) T[j] = as_v2s(col[j]);
+            v2s mm = T[0];
+#pragma unroll
+            for (int j = 1; j < 16 * NP; j++) mm = vmin(mm, T[j]);
+            const int minS = min((int)mm.x, (int)mm.y);
+            int best = 1 << 20, cnt = 0;
+#pragma unroll
+            for (int j = 16 * NP - 1; j >= 0; j--) {
+                if ((int)T[j].y == minS) { best = 2 * j + 1; cnt++; }
+                if ((int)T[j].x == minS) { best = 2 * j; cnt++; }
             }
-            out[x0 + lane16] = (int)(((unsigned)kminS << 16) | ((unsigned)d16 & 0xffffu));
+            if (tie_lanes > 0 && cnt > 1) {
+                // vectorised-loop rule: per SIMD lane class the last tie, then the smallest of those
+                int bb = 1 << 20;
+                for (int c = 0; c < tie_lanes; c++) {
+                    int last = -1;
+                    for (int d = c; d < D; d += tie_lanes) if ((int)col16[d] == minS) last = d;
+                    if (last >= 0) bb = min(bb, last);
+                }
+                best = bb;
+            }
+            if (active && lane16 < cols) {
+                int d16 = best * 16;
+                if (best > 0 && best < D - 1) {
+                    const int sm = col16[best - 1], sp = col16[best + 1];
+                    const int denom2 = max(sm + sp - 2 * minS, 1);
+                    d16 += ((sm - sp) * 16 + denom2) / (denom2 * 2);
+                }
+                out[x0 + lane16] = (int)(((unsigned)minS << 16) | ((unsigned)d16 & 0xffffu));
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
 #pragma unroll
         for (int u = 0; u < HP_SEG; u++)
 #pragma unroll
@@ -787,26 +667,21 @@ int run_sgbm(vo_ctx* c)
         hipLaunchKernelGGL((cost_vpath_kernel<NP, 0>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
                            SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring, lds_slots);
     }
-#ifdef VO_HPATH_STORE_LLR
-    { StageTimer st_(c, VO_ST_HPATH_FWD);
-    hipLaunchKernelGGL((hpath_kernel<NP, false>), dim3((c->srows + 15) / 16, n), dim3(256), 0, c->stream, c->cost, c->agg, w1, D, W,
-                       c->srows, c->P1, c->P2, c->p.wta_simd_lanes, c->wta);
-    }
-    { StageTimer st_(c, VO_ST_HPATH_BWD);
-    hipLaunchKernelGGL((hpath_kernel<NP, true>), dim3((c->srows + 15) / 16, n), dim3(256), 0, c->stream, c->cost, c->agg, w1, D, W,
-                       c->srows, c->P1, c->P2, c->p.wta_simd_lanes, c->wta);
-    }
-#else
     const int nseg = vo_hpath_segments(c);
     { StageTimer st_(c, VO_ST_HPATH_FWD);
     hipLaunchKernelGGL((hpath_ckpt_kernel<NP>), dim3((H + 15) / 16, n), dim3(256), 0, c->stream, c->cost, w1, D, H, c->srows, si, c->stripe_sz,
                        c->P1, c->P2, nseg, c->ckpt);
     }
     { StageTimer st_(c, VO_ST_HPATH_BWD);
-    hipLaunchKernelGGL((hpath_resolve_kernel<NP>), dim3((H + 15) / 16, n), dim3(256), 0, c->stream, c->cost, c->agg, w1, D, W, H, c->srows, si,
+    const size_t hp_lds = (size_t)4 * vo_hpath_seg(NP) * (16 * NP + 1) * sizeof(int);
+    static bool hp_attr_set = false;
+    if (hp_lds > 48 * 1024 && !hp_attr_set) {
+        VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&hpath_resolve_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hp_lds));
+        hp_attr_set = true;
+    }
+    hipLaunchKernelGGL((hpath_resolve_kernel<NP>), dim3((H + 3) / 4, n), dim3(64), hp_lds, c->stream, c->cost, c->agg, w1, D, W, H, c->srows, si,
                        c->stripe_sz, c->P1, c->P2, c->p.wta_simd_lanes, nseg, c->ckpt, c->wta);
     }
-#endif
     { StageTimer st_(c, VO_ST_LRCHECK);
     hipLaunchKernelGGL(lrcheck_kernel, dim3(H, n), dim3(256), (size_t)W * 4, c->stream, c->wta, W, H, w1, c->srows, si, c->stripe_sz,
                        c->disp12, c->disp_pre);
