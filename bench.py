@@ -125,10 +125,17 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if "VO_BENCH_DEVICE" in os.environ:  # rehearsal of the multi-rank path on a box with fewer GPUs than ranks
+        local_rank = int(os.environ["VO_BENCH_DEVICE"])
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # RCCL ("nccl") is the backend of a real run; gloo only for rehearsing the multi-rank flow on one GPU
+        backend = os.environ.get("VO_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
     torch.cuda.set_device(local_rank)
@@ -202,7 +209,8 @@ def main():
         c.synchronize()
     torch.cuda.synchronize()
     # the only collective: gather the per-frame relative poses of every rank (result gather, RCCL over xGMI)
-    poses = torch.from_numpy(Rt).to(dev)
+    cdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
+    poses = torch.from_numpy(Rt).to(cdev)
     if world > 1:
         gathered = [torch.empty_like(poses) for _ in range(world)]
         dist.all_gather(gathered, poses)
@@ -210,7 +218,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 

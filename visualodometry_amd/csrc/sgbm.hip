@@ -42,24 +42,6 @@ __device__ __forceinline__ int row_min(int v)
     v = min(v, DPP_STEP(v, 0x141)); v = min(v, DPP_STEP(v, 0x140));
     return v;
 }
-__device__ __forceinline__ int row_max(int v)
-{
-    v = max(v, DPP_STEP(v, 0xB1)); v = max(v, DPP_STEP(v, 0x4E));
-    v = max(v, DPP_STEP(v, 0x141)); v = max(v, DPP_STEP(v, 0x140));
-    return v;
-}
-__device__ __forceinline__ int row_add(int v)
-{
-    v += DPP_STEP(v, 0xB1); v += DPP_STEP(v, 0x4E);
-    v += DPP_STEP(v, 0x141); v += DPP_STEP(v, 0x140);
-    return v;
-}
-__device__ __forceinline__ int row_or(int v)
-{
-    v |= DPP_STEP(v, 0xB1); v |= DPP_STEP(v, 0x4E);
-    v |= DPP_STEP(v, 0x141); v |= DPP_STEP(v, 0x140);
-    return v;
-}
 // value of the previous / next lane of the row; `edge` where there is none
 __device__ __forceinline__ int row_from_prev(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x111, 0xF, 0xF, false); }
 __device__ __forceinline__ int row_from_next(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x101, 0xF, 0xF, false); }
