@@ -748,7 +748,9 @@ int estimate_motion_batch(vo_ctx* c, double* Rt_out, vo_frame_info* info)
 {
     hipStream_t bulk = c->stream;
     VO_HIP(c, hipStreamSynchronize(bulk));
+#ifndef VO_NO_HI_STREAM
     if (c->stream_hi) c->stream = c->stream_hi;
+#endif
     const int rc = estimate_motion_rounds(c, Rt_out, info);
     c->stream = bulk;
     return rc;

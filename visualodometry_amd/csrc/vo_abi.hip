@@ -7,8 +7,14 @@
 #include <math.h>
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 
 static thread_local std::string g_create_err;
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_hi_mu;
+static hipStream_t g_hi_stream[kMaxDevices];
+static int g_hi_users[kMaxDevices];
 
 int vo_fail(vo_ctx* c, int code, const char* fmt, ...)
 {
@@ -109,7 +115,7 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return vo_fail(nullptr, VO_ERR_NO_DEVICE, "no HIP device available");
-    if (device < 0 || device >= ndev) return vo_fail(nullptr, VO_ERR_BAD_ARG, "device %d out of range (%d devices)", device, ndev);
+    if (device < 0 || device >= ndev || device >= kMaxDevices) return vo_fail(nullptr, VO_ERR_BAD_ARG, "device %d out of range (%d devices)", device, ndev);
     vo_ctx* c = new vo_ctx();
     c->p = *p; c->device = device;
     memset(c->ev0, 0, sizeof(c->ev0)); memset(c->ev1, 0, sizeof(c->ev1)); memset(c->ev_used, 0, sizeof(c->ev_used));
@@ -123,9 +129,16 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     CR(hipSetDevice(device));
     CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     {
-        int least = 0, greatest = 0;
-        CR(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        CR(hipStreamCreateWithPriority(&c->stream_hi, hipStreamNonBlocking, greatest));
+        // one high-priority stream per device for all contexts: a process has few hardware queues (4 by default), and
+        // every extra stream beyond them shares a queue with, and so serialises behind, some other stream
+        std::lock_guard<std::mutex> lk(g_hi_mu);
+        if (!g_hi_stream[device]) {
+            int least = 0, greatest = 0;
+            CR(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            CR(hipStreamCreateWithPriority(&g_hi_stream[device], hipStreamNonBlocking, greatest));
+        }
+        c->stream_hi = g_hi_stream[device];
+        g_hi_users[device]++;
     }
     const size_t B = c->p.max_batch, W = c->W, H = c->H, D = c->D, w1 = c->width1, F = c->p.max_features;
     c->own_pitch = (W + 63) & ~(size_t)63; c->own_fstride = c->own_pitch * H;
@@ -181,7 +194,10 @@ extern "C" void vo_destroy(vo_ctx* c)
     if (c->host_pool) pnp_host::destroy_pool(c->host_pool);
     if (c->step_done) (void)hipEventDestroy(c->step_done);
     for (int i = 0; i < VO_NUM_STAGES; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
-    if (c->stream_hi) (void)hipStreamDestroy(c->stream_hi);
+    if (c->stream_hi) {
+        std::lock_guard<std::mutex> lk(g_hi_mu);
+        if (--g_hi_users[c->device] == 0) { (void)hipStreamDestroy(g_hi_stream[c->device]); g_hi_stream[c->device] = nullptr; }
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
