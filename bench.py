@@ -269,6 +269,14 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": stage_ms.get(dom, 0.0)},
         }
+        # the same figures for every kernel with a byte model (the tracker and the resolve pass are bound by vector
+        # instruction issue, not by HBM: their fractions say how far from the memory roof they sit, not how good they are)
+        out["roofline"]["per_kernel"] = {
+            k: {"algorithmic_GB_per_launch": round(kb[k] / 1e9, 4), "avg_launch_ms": round(stage_ms.get(k, 0.0), 4),
+                "frac": round(kb[k] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if stage_ms.get(k, 0) > 0 else None,
+                "avg_launch_ms_one_batch_in_flight": round(isolated.get(k, 0.0), 4),
+                "frac_one_batch_in_flight": round(kb[k] / (isolated[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if isolated.get(k, 0) > 0 else None}
+            for k in kb}
         if isolated.get(dom, 0) > 0:
             iso = kb[dom] / (isolated[dom] * 1e-3) / 1e9
             out["roofline"].update({"avg_launch_ms_one_batch_in_flight": isolated[dom], "achieved_one_batch_in_flight": iso,

@@ -136,6 +136,9 @@ void build_pyramid(const uint8_t* img, int w, int h, int win, int levels, bool w
 
 /* statistics for tuning the GPU tracker: window setups that reached the iteration loop, and iterations */
 static long long g_lk_levels = 0, g_lk_iters = 0, g_lk_hist[52];
+/* optional log of iterations per (call, level, point), in call order; for tuning, single-threaded runs only */
+static int* g_lk_log = nullptr;
+static long long g_lk_log_pos = 0, g_lk_log_cap = 0;
 
 /* LKTrackerInvoker for one point on one level. */
 void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, orc_point2f* next_pt_io,
@@ -267,9 +270,12 @@ void lk_with_pyramids(const Pyr& P, const Pyr& N, const orc_point2f* prev_pts, i
 
     for (int level = levels; level >= 0; level--) {
 #pragma omp parallel for num_threads(orc_get_threads()) schedule(static)
-        for (int i = 0; i < n; i++)
+        for (int i = 0; i < n; i++) {
+            const long long before = g_lk_iters;
             track_point(P.lv[level], N.lv[level], prev_pts[i], &next_pts[i], &status[i], err ? &err[i] : nullptr,
                         level, levels, p->lk_win, max_count, eps2, (float)p->lk_min_eig);
+            if (g_lk_log && g_lk_log_pos < g_lk_log_cap) g_lk_log[g_lk_log_pos++] = (int)(g_lk_iters - before); /* single-threaded runs only */
+        }
     }
 }
 
@@ -338,6 +344,8 @@ extern "C" void orc_lk_stats(long long* levels, long long* iters, int reset)
     *levels = g_lk_levels; *iters = g_lk_iters;
     if (reset) { g_lk_levels = 0; g_lk_iters = 0; }
 }
+extern "C" void orc_lk_set_log(int* buf, long long capacity) { g_lk_log = buf; g_lk_log_pos = 0; g_lk_log_cap = capacity; }
+extern "C" long long orc_lk_log_size(void) { return g_lk_log_pos; }
 extern "C" void orc_lk_hist(long long* out52, int reset)
 {
     for (int i = 0; i < 52; i++) { out52[i] = g_lk_hist[i]; if (reset) g_lk_hist[i] = 0; }

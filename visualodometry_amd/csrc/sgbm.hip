@@ -635,10 +635,10 @@ int run_sgbm(vo_ctx* c)
                         : (int)std::min<size_t>((VO_COST_LDS_BUDGET - tile_bytes) / slot_bytes, (size_t)(2 * SH2 + 2));
     const size_t lds = tile_bytes + lds_slots * slot_bytes;
     const void* fn = swc ? reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 5>) : reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 0>);
-    static bool lds_attr_set[2] = {false, false};
-    if (lds > 48 * 1024 && !lds_attr_set[swc ? 1 : 0]) {
+    static bool lds_attr_set[64][2]; // per device: a kernel's attributes belong to the device's copy of the code object
+    if (lds > 48 * 1024 && !lds_attr_set[c->device & 63][swc ? 1 : 0]) {
         VO_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_attr_set[swc ? 1 : 0] = true;
+        lds_attr_set[c->device & 63][swc ? 1 : 0] = true;
     }
     const int tile_out = CV_COLS - 2 * SH2;
     const dim3 grid((w1 + tile_out - 1) / tile_out, 4, n), blk(VO_COST_THREADS);
@@ -656,10 +656,10 @@ int run_sgbm(vo_ctx* c)
     }
     { StageTimer st_(c, VO_ST_HPATH_BWD);
     const size_t hp_lds = (size_t)4 * vo_hpath_seg(NP) * (16 * NP + 1) * sizeof(int);
-    static bool hp_attr_set = false;
-    if (hp_lds > 48 * 1024 && !hp_attr_set) {
+    static bool hp_attr_set[64];
+    if (hp_lds > 48 * 1024 && !hp_attr_set[c->device & 63]) {
         VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&hpath_resolve_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hp_lds));
-        hp_attr_set = true;
+        hp_attr_set[c->device & 63] = true;
     }
     hipLaunchKernelGGL((hpath_resolve_kernel<NP>), dim3((H + 3) / 4, n), dim3(64), hp_lds, c->stream, c->cost, c->agg, w1, D, W, H, c->srows, si,
                        c->stripe_sz, c->P1, c->P2, c->p.wta_simd_lanes, nseg, c->ckpt, c->wta);
