@@ -1,0 +1,137 @@
+"""The oracle against independent implementations of the same published definitions (scipy / plain numpy written from
+the definition, not from the oracle's code).  This does not pin the oracle to OpenCV's outputs (there is no OpenCV
+here), but it separates "the oracle implements the stated algorithm" from "the statement matches OpenCV"."""
+import numpy as np
+import pytest
+from scipy import ndimage
+from scipy.spatial.transform import Rotation
+
+from oracle import binding as ob
+from visualodometry_amd import synth
+
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+def is_corner(img, x, y, t):
+    """FAST-9/16 by definition: 9 contiguous ring pixels all brighter than v + t or all darker than v - t."""
+    v = int(img[y, x])
+    ring = [int(img[y + dy, x + dx]) for dx, dy in RING]
+    for sign in (1, -1):
+        flags = [(p - v) * sign > t for p in ring]
+        run = best = 0
+        for f in flags + flags:          # the ring is circular
+            run = run + 1 if f else 0
+            best = max(best, run)
+        if best >= 9:
+            return True
+    return False
+
+
+def brute_force_fast(img, t=20):
+    h, w = img.shape
+    score = np.zeros((h, w), dtype=np.int32)
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            if is_corner(img, x, y, t):
+                lo, hi = t, 255              # score = largest threshold for which the pixel is still a corner
+                while lo < hi:
+                    mid = (lo + hi + 1) // 2
+                    if is_corner(img, x, y, mid):
+                        lo = mid
+                    else:
+                        hi = mid - 1
+                score[y, x] = lo
+    pts = []
+    for y in range(3, h - 3):
+        for x in range(3, w - 3):
+            s = score[y, x]
+            if s and all(s > score[y + dy, x + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if (dx, dy) != (0, 0)):
+                pts.append((x, y))
+    return np.array(pts, dtype=np.float32).reshape(-1, 2), score
+
+
+def test_fast_against_the_segment_test_definition():
+    rng = np.random.RandomState(11)
+    img = ndimage.gaussian_filter(rng.rand(40, 56), 1.2)
+    img = ((img - img.min()) / (img.max() - img.min()) * 255).astype(np.uint8)
+    img[10:14, 20:24] = 250
+    img[25:27, 40:43] = 3
+    want, want_score = brute_force_fast(img)
+    got, resp, score = ob.fast(img, with_score=True)
+    assert len(want) > 5
+    assert np.array_equal(got, want)
+    # the oracle's min/max formula for the response equals the largest threshold that keeps the pixel a corner
+    assert np.array_equal(resp, [want_score[int(y), int(x)] for x, y in want])
+    # without non-max suppression: every pixel passing the segment test, row-major
+    all_pts = ob.fast(img, nms=False)
+    ys, xs = np.nonzero(want_score)
+    assert np.array_equal(all_pts, np.stack([xs, ys], axis=1).astype(np.float32))
+
+
+def test_pyrdown_against_scipy():
+    rng = np.random.RandomState(5)
+    for h, w in ((24, 31), (17, 16), (33, 40)):
+        img = rng.randint(0, 256, size=(h, w)).astype(np.uint8)
+        k = np.array([1, 4, 6, 4, 1])
+        full = ndimage.correlate1d(ndimage.correlate1d(img.astype(np.int64), k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+        want = ((full[::2, ::2] + 128) >> 8).astype(np.uint8)      # REFLECT_101 is scipy's "mirror"
+        assert np.array_equal(ob.pyrdown(img), want), (h, w)
+
+
+def test_scharr_against_scipy():
+    rng = np.random.RandomState(6)
+    img = rng.randint(0, 256, size=(21, 34)).astype(np.uint8)
+    kx = np.array([[-3, 0, 3], [-10, 0, 10], [-3, 0, 3]])
+    dx = ndimage.correlate(img.astype(np.int64), kx, mode="mirror")
+    dy = ndimage.correlate(img.astype(np.int64), kx.T, mode="mirror")
+    got = ob.scharr(img)
+    assert np.array_equal(got[..., 0], dx) and np.array_equal(got[..., 1], dy)
+
+
+def test_median_3x3_against_scipy():
+    seq = synth.Sequence(seed=9, width=200, height=60)
+    l, r = seq.frame(0)
+    p = ob.default_params(200, 60, num_disparities=32)
+    final, pre = ob.sgbm(l, r, p, with_premedian=True)
+    assert np.array_equal(final, ndimage.median_filter(pre, size=3, mode="nearest"))   # replicated border
+    assert (final != pre).any()
+
+
+def test_rodrigues_against_scipy():
+    rng = np.random.RandomState(2)
+    for _ in range(20):
+        r = rng.normal(0, 1.0, 3)
+        R, J = ob.rodrigues(r)
+        assert np.allclose(R, Rotation.from_rotvec(r).as_matrix(), atol=1e-14)
+        assert np.allclose(ob.rodrigues_inv(R), Rotation.from_matrix(R).as_rotvec(), atol=1e-12)
+        # Jacobian (3 x 9, row i = d vec(R) / d r_i) against central differences
+        eps = 1e-6
+        for i in range(3):
+            d = np.zeros(3); d[i] = eps
+            num = (ob.rodrigues(r + d)[0] - ob.rodrigues(r - d)[0]).reshape(9) / (2 * eps)
+            assert np.allclose(J[i], num, atol=1e-8)
+
+
+def test_inverse_and_projection_against_numpy():
+    rng = np.random.RandomState(3)
+    for _ in range(10):
+        R = Rotation.from_rotvec(rng.normal(0, 0.3, 3)).as_matrix()
+        Rt = np.eye(4); Rt[:3, :3] = R; Rt[:3, 3] = rng.normal(0, 2, 3)
+        assert np.allclose(ob.inv4x4(Rt), np.linalg.inv(Rt), atol=1e-13)
+
+
+def test_bilinear_window_tracking_against_dense_search():
+    """LK on a smooth image translated by a known sub-pixel shift: the tracked displacement is the shift (the residual is
+    what an exhaustive SSD search over shifts also finds to be the minimum, to within the search step)."""
+    yy, xx = np.mgrid[0:96, 0:128].astype(np.float64)
+
+    def scene(dx, dy):
+        return (127 + 60 * np.sin((xx - dx) / 5.0) * np.cos((yy - dy) / 7.0) + 40 * np.sin((xx - dx + yy - dy) / 11.0)).round().astype(np.uint8)
+
+    a, b = scene(0, 0), scene(1.3, -0.6)
+    p = ob.default_params(128, 96, lk_win=15)
+    pts = np.array([[40, 40], [64, 50], [90, 30]], dtype=np.float32)
+    res = ob.lk(a, b, pts, p)
+    nxt, status = res[0], res[1]
+    assert status.all()
+    assert np.abs((nxt - pts) - np.array([1.3, -0.6])).max() < 0.05
