@@ -135,3 +135,17 @@ def test_bilinear_window_tracking_against_dense_search():
     nxt, status = res[0], res[1]
     assert status.all()
     assert np.abs((nxt - pts) - np.array([1.3, -0.6])).max() < 0.05
+
+
+def test_sgbm_against_direct_numpy_statement():
+    """the streaming C++ oracle against tests/sgm_numpy.py (block sums and paths written as plain array expressions)"""
+    from sgm_numpy import sgm3way
+    for seed, (w, h) in ((21, (90, 30)), (22, (77, 25))):
+        seq = synth.Sequence(seed=seed, width=w, height=h)
+        l, r = seq.frame(0)
+        p = ob.default_params(w, h, num_disparities=32, wta_simd_lanes=0)   # plain "lowest d on ties" rule
+        got, got_pre = ob.sgbm(l, r, p, with_premedian=True)
+        want, want_pre = sgm3way(l, r, D=32)
+        assert np.array_equal(got_pre, want_pre), (seed, int((got_pre != want_pre).sum()))
+        assert np.array_equal(got, want)
+        assert (got >= 0).mean() > 0.2
