@@ -242,8 +242,13 @@ def main():
         kb = kernel_bytes(W, H, D, srows, B)
         stage_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in timing.items()}
         log("[stage ms per launch] " + ", ".join("%s=%.3f" % kv for kv in stage_ms.items()))
-        dom = max(kb, key=lambda k: stage_ms.get(k, 0.0))
-        achieved = kb[dom] / (stage_ms[dom] * 1e-3) / 1e9 if stage_ms.get(dom, 0) > 0 else 0.0
+        # Kernel durations.  With several batches in flight the kernels of different batches share the GPU, so an event
+        # pair around a launch measures a co-scheduled kernel (and rocprofv3, which serialises dispatches, would not
+        # agree with it).  The roofline therefore uses the one-batch-in-flight pass made right after the timed region
+        # (same process, same inputs, same HIP-event timers on the kernels' stream); the timed-region figures ride along.
+        excl = isolated if isolated else stage_ms
+        dom = max(kb, key=lambda k: excl.get(k, 0.0))
+        achieved = kb[dom] / (excl[dom] * 1e-3) / 1e9 if excl.get(dom, 0) > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
@@ -251,6 +256,10 @@ def main():
                 traffic = json.load(open(tf)).get(args.workload, {}).get(dom)
             except Exception:
                 traffic = None
+
+        def frac(ms, k):
+            return round(kb[k] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms.get(k, 0) > 0 else None
+
         out = {
             "metric": "stereo frames/sec at 1241x376 (1/2/4/8 GPU) + achieved HBM GB/s vs roofline",
             "value": fps, "unit": "stereo frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -263,25 +272,20 @@ def main():
                        "mpix_per_s": fps * W * H / 1e6,
                        "features_per_frame": int(np.mean([i.n_features for i in info])),
                        "matches_per_frame": int(np.mean([i.n_matched for i in info])),
-                       "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+                       "stage_ms_timed_region": {k: round(v, 4) for k, v in stage_ms.items()},
+                       "stage_ms_one_batch_in_flight": {k: round(v, 4) for k, v in excl.items()},
                        "whole_path_algorithmic_GBs": frame_bytes(W, H, D) * fps / world / 1e9},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": stage_ms.get(dom, 0.0)},
+                         "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": excl.get(dom, 0.0),
+                         "avg_launch_ms_timed_region": stage_ms.get(dom, 0.0), "frac_timed_region": frac(stage_ms, dom),
+                         "measured": "HIP events on the kernel's stream, one batch in flight, right after the timed region"
+                                     if isolated else "HIP events on the kernel's stream over the timed region",
+                         # the tracker and the resolve pass are bound by vector instruction issue, not by HBM: their
+                         # fractions say how far below the memory roof they sit
+                         "per_kernel": {k: {"algorithmic_GB_per_launch": round(kb[k] / 1e9, 4), "avg_launch_ms": round(excl.get(k, 0.0), 4),
+                                            "frac": frac(excl, k), "avg_launch_ms_timed_region": round(stage_ms.get(k, 0.0), 4)} for k in kb}},
         }
-        # the same figures for every kernel with a byte model (the tracker and the resolve pass are bound by vector
-        # instruction issue, not by HBM: their fractions say how far from the memory roof they sit, not how good they are)
-        out["roofline"]["per_kernel"] = {
-            k: {"algorithmic_GB_per_launch": round(kb[k] / 1e9, 4), "avg_launch_ms": round(stage_ms.get(k, 0.0), 4),
-                "frac": round(kb[k] / (stage_ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if stage_ms.get(k, 0) > 0 else None,
-                "avg_launch_ms_one_batch_in_flight": round(isolated.get(k, 0.0), 4),
-                "frac_one_batch_in_flight": round(kb[k] / (isolated[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if isolated.get(k, 0) > 0 else None}
-            for k in kb}
-        if isolated.get(dom, 0) > 0:
-            iso = kb[dom] / (isolated[dom] * 1e-3) / 1e9
-            out["roofline"].update({"avg_launch_ms_one_batch_in_flight": isolated[dom], "achieved_one_batch_in_flight": iso,
-                                    "frac_one_batch_in_flight": iso / HBM_PEAK_GBS})
-            out["config"]["stage_ms_one_batch_in_flight"] = {k: round(v, 4) for k, v in isolated.items()}
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(frames, seq, shape, args.cpu_pairs)
         print(json.dumps(out), flush=True)
