@@ -177,7 +177,12 @@ int vo_step(vo_ctx* ctx, double* Rt_out /* n*16 */, vo_frame_info* info /* nulla
 /* The same step in two halves, so that a caller with two contexts can overlap the host part (minimal
  * solvers, final refine) of one batch with the GPU part of the next: vo_step_submit enqueues every GPU
  * stage and returns without waiting; vo_step_finish waits for them and runs the host part.
- * vo_step(ctx, ...) == vo_step_submit(ctx) followed by vo_step_finish(ctx, ...). */
+ * vo_step(ctx, ...) == vo_step_submit(ctx) followed by vo_step_finish(ctx, ...).
+ * Streams: a context enqueues on one stream of its own; the pose solver's short round trips use one
+ * high-priority stream shared by all contexts of a device.  A process has few hardware queues (4 unless
+ * GPU_MAX_HW_QUEUES says otherwise), so three contexts in flight is the sweet spot for throughput.  With the
+ * environment variable VO_DUAL_STREAM set when a context is created, the corner / tracking chain of a step
+ * runs on a second stream beside the disparity chain: lower latency for a single context, no gain with three. */
 int vo_step_submit(vo_ctx* ctx);
 int vo_step_finish(vo_ctx* ctx, double* Rt_out /* n*16 */, vo_frame_info* info /* nullable, n */);
 

@@ -3,6 +3,7 @@
 #include "pnp_host.h"
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <algorithm>
@@ -140,6 +141,10 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
         c->stream_hi = g_hi_stream[device];
         g_hi_users[device]++;
     }
+    if (getenv("VO_DUAL_STREAM")) {
+        CR(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        CR(hipEventCreateWithFlags(&c->join2, hipEventDisableTiming));
+    }
     const size_t B = c->p.max_batch, W = c->W, H = c->H, D = c->D, w1 = c->width1, F = c->p.max_features;
     c->own_pitch = (W + 63) & ~(size_t)63; c->own_fstride = c->own_pitch * H;
     CR(dalloc(&c->img_own, 4 * B * c->own_fstride));
@@ -198,6 +203,8 @@ extern "C" void vo_destroy(vo_ctx* c)
         std::lock_guard<std::mutex> lk(g_hi_mu);
         if (--g_hi_users[c->device] == 0) { (void)hipStreamDestroy(g_hi_stream[c->device]); g_hi_stream[c->device] = nullptr; }
     }
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->join2) (void)hipEventDestroy(c->join2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -541,10 +548,19 @@ extern "C" int vo_step_submit(vo_ctx* c)
     // every GPU stage is enqueued back to back without a host round trip
     if ((rc = launch_sgbm(c))) return rc;
     c->have_disp = true; c->have_depth = false;
-    if ((rc = launch_fast(c))) return rc;
-    if ((rc = launch_pyramids(c))) return rc;
-    c->have_pyr = true;
-    if ((rc = launch_match_klt(c, false))) return rc;
+    // disparity and the corner / tracking chain are independent until triangulation: with a second stream the
+    // instruction-bound tracker runs beside the bandwidth-bound cost volume passes of the same batch
+    hipStream_t main_stream = c->stream;
+    if (c->stream2) c->stream = c->stream2;
+    rc = launch_fast(c);
+    if (!rc) rc = launch_pyramids(c);
+    if (!rc) { c->have_pyr = true; rc = launch_match_klt(c, false); }
+    if (c->stream2) {
+        if (!rc && hipEventRecord(c->join2, c->stream2) != hipSuccess) rc = vo_fail(c, VO_ERR_HIP, "hipEventRecord failed");
+        c->stream = main_stream;
+        if (!rc && hipStreamWaitEvent(c->stream, c->join2, 0) != hipSuccess) rc = vo_fail(c, VO_ERR_HIP, "hipStreamWaitEvent failed");
+    }
+    if (rc) return rc;
     if ((rc = launch_triangulate(c))) return rc;
     VO_HIP(c, hipMemcpyAsync(c->h_counts, c->n_feat, c->n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     VO_HIP(c, hipMemcpyAsync(c->h_counts + c->p.max_batch, c->n_match, c->n * sizeof(int), hipMemcpyDeviceToHost, c->stream));

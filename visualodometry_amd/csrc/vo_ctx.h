@@ -25,6 +25,8 @@ struct vo_ctx {
     vo_params p;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // optional: corner / tracking chain of a step, beside the disparity chain on `stream`
+    hipEvent_t join2 = nullptr;
     hipStream_t stream_hi = nullptr; // highest priority: the short scoring round trips of the pose solver
     std::string err;
 
