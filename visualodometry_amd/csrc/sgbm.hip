@@ -143,8 +143,9 @@ template <int NP>
 __device__ __forceinline__ void store_pk(int16_t* __restrict__ p, const v2s (&v)[NP])
 {
     int* q = reinterpret_cast<int*>(p);
+    // streamed out once and read back by later kernels only: keep it from displacing the ring and the image rows in cache
 #pragma unroll
-    for (int k = 0; k < NP; k++) q[k] = as_int(v[k]);
+    for (int k = 0; k < NP; k++) __builtin_nontemporal_store(as_int(v[k]), q + k);
 }
 
 // y0: first source row a stripe walks (warm-up included), out0: first row whose results are used, off: stripe-row offset
