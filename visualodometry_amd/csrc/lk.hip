@@ -161,11 +161,20 @@ __device__ __forceinline__ float group_sum(int v)
 }
 
 // two sums at once: four independent DPP chains, stepped together so no step waits on the previous one
+// QUAD32: the per-lane values are small enough (|value| < 2^29) for the first two steps, which add four lanes, to run on
+// the whole 32-bit values; only the last two steps then need the split halves
+template <bool QUAD32>
 __device__ __forceinline__ void group_sum2(int u, int v, float& su, float& sv)
 {
+    if (QUAD32) {
+        int t0 = __builtin_amdgcn_update_dpp(0, u, 0xB1, 0xF, 0xF, false), t1 = __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false);
+        u += t0; v += t1;
+        t0 = __builtin_amdgcn_update_dpp(0, u, 0x4E, 0xF, 0xF, false); t1 = __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false);
+        u += t0; v += t1;
+    }
     int c[4] = {u & 0xffff, u >> 16, v & 0xffff, v >> 16};
 #pragma unroll
-    for (int s = 0; s < 4; s++) { // the DPP control must be a literal, hence the chain of selects on the unrolled step
+    for (int s = QUAD32 ? 2 : 0; s < 4; s++) { // the DPP control must be a literal, hence the chain of selects on the unrolled step
         int t[4];
 #pragma unroll
         for (int q = 0; q < 4; q++)
@@ -176,7 +185,7 @@ __device__ __forceinline__ void group_sum2(int u, int v, float& su, float& sv)
 #pragma unroll
         for (int q = 0; q < 4; q++) c[q] += t[q];
     }
-    su =(float)((double)c[1] * 65536.0 + (double)c[0]);
+    su = (float)((double)c[1] * 65536.0 + (double)c[0]);
     sv = (float)((double)c[3] * 65536.0 + (double)c[2]);
 }
 
@@ -277,10 +286,10 @@ __global__ __launch_bounds__(256) void lk_row_kernel(LkArgs a, const uint8_t* __
                     int ixv[NPX + 1], iyv[NPX + 1];
 #pragma unroll
                     for (int x = 0; x < NPX; x++) {
-                        const int iv = dot2(pr[k + 1][x], w1, dot2(pr[k][x], w0, 1 << 8)) >> 9;
+                        const int iv = dot2(pr[k + 1][x], w1, dot2_keep(pr[k][x], w0, 1 << 8)) >> 9;
                         C0[k][x] = (1 << 8) - (iv << 9);
-                        ixv[x] = dot2(dx[k + 1][x], wd1, dot2(dx[k][x], wd0, 1 << 13)) >> 14;
-                        iyv[x] = dot2(dy[k + 1][x], wd1, dot2(dy[k][x], wd0, 1 << 13)) >> 14;
+                        ixv[x] = dot2(dx[k + 1][x], wd1, dot2_keep(dx[k][x], wd0, 1 << 13)) >> 14;
+                        iyv[x] = dot2(dy[k + 1][x], wd1, dot2_keep(dy[k][x], wd0, 1 << 13)) >> 14;
                     }
                     ixv[NPX] = 0; iyv[NPX] = 0;
 #pragma unroll
@@ -336,7 +345,8 @@ __global__ __launch_bounds__(256) void lk_row_kernel(LkArgs a, const uint8_t* __
                             }
                         }
                         float b1, b2;
-                        group_sum2(sb1, sb2, b1, b2);
+                        // one window row of at most 15 products per lane, each below 2^25: four lanes stay below 2^31
+                        group_sum2<NR == 1 && NDW <= 4>(sb1, sb2, b1, b2);
                         b1 *= FLT_SCALE; b2 *= FLT_SCALE;
                         const float dx_ = (A12 * b2 - A22 * b1) * Dt, dy_ = (A12 * b1 - A11 * b2) * Dt;
                         qx += dx_; qy += dy_;
