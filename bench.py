@@ -286,7 +286,7 @@ def main():
                          "per_kernel": {k: {"algorithmic_GB_per_launch": round(kb[k] / 1e9, 4), "avg_launch_ms": round(excl.get(k, 0.0), 4),
                                             "frac": frac(excl, k), "avg_launch_ms_timed_region": round(stage_ms.get(k, 0.0), 4)} for k in kb}},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:   # the CPU baseline is a single-GPU-run item
             out["cpu_baseline"] = cpu_baseline(frames, seq, shape, args.cpu_pairs)
         print(json.dumps(out), flush=True)
     if world > 1:
