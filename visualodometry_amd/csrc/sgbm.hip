@@ -152,25 +152,26 @@ __device__ __forceinline__ void store_pk(int16_t* __restrict__ p, const v2s (&v)
 struct StripeInfo { int y0[4], rows[4], off[4], out0[4]; };
 
 // ---------------------------------------------------------------- pixel cost + 11x11 window + top-down path, fused
-// Block = VO_COST_THREADS threads in lane groups of 16; a lane group owns 4 adjacent tile columns (CV_COLS per block,
+// Block = VO_COST_THREADS threads in lane groups of 16; a lane group owns NCOL adjacent tile columns (CV_COLS per block,
 // SW2 of them on each side are halo), a lane 2*NP consecutive disparities of each.  Marching down the stripe:
 //   V(x, d)  = running vertical window sum of the pixel cost.  The row that enters the window is evaluated from the
 //              prefiltered rows; the row that leaves it was evaluated block_size steps earlier by the same thread and
 //              comes back from a per-thread ring of byte costs in global memory (a cost is at most 30 + 63, so 4 cells
 //              per dword; the ring has block_size + 1 slots so the slot read and the slot written always differ),
-//   C(x, d)  = horizontal window sum of V through LDS (sliding over the group's 4 columns),
+//   C(x, d)  = horizontal window sum of V through LDS (sliding over the group's columns),
 //   L_top    = one path step per column; C and L_top are the only HBM traffic (one write each).
-constexpr int CV_COLS = VO_COST_TILE_COLS;
 
 // SWC: the half window as a compile-time constant (0 = use the run-time SW2; slower horizontal sum)
-template <int NP, int SWC>
+// NCOL: tile columns per lane group (4; 2 for wide disparity ranges, where 4 columns x 2NP cells do not fit the registers)
+template <int NP, int SWC, int NCOL>
 __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2* __restrict__ pre, int W, int H, int Wp, int width1, int D, int SW2,
                                                          int srows, StripeInfo si, int P1, int P2, int16_t* __restrict__ cost,
                                                          int16_t* __restrict__ agg, uint32_t* __restrict__ ring, int lds_slots)
 {
+    constexpr int CV_COLS = (VO_COST_THREADS / 16) * NCOL;
     extern __shared__ int vt[]; // [2][CV_COLS][CS]: V of every tile column, dword (k, lane16) at k*16 + lane16
     constexpr int CS = 16 * NP + 4;
-    constexpr int NR = 2 * NP + 3;
+    constexpr int NR = 2 * NP + NCOL - 1;
     const int lane16 = threadIdx.x & 15, q = threadIdx.x >> 4;
     const int stripe = blockIdx.y, b = blockIdx.z;
     const int y0 = si.y0[stripe], rows = si.rows[stripe];
@@ -178,27 +179,27 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
     const int tile_out = CV_COLS - 2 * SW2;
     const int xc0 = blockIdx.x * tile_out - SW2; // cost column of tile column 0
     const int minX1 = W - width1;
-    const int cb = q * 4;
+    const int cb = q * NCOL;
     const int d0 = lane16 * 2 * NP;
     const uint2* Lb = pre + ((size_t)b * 2 + 0) * H * Wp;
     const uint2* Rb = pre + ((size_t)b * 2 + 1) * H * Wp;
-    unsigned xl[4]; // unsigned byte offsets from a uniform row pointer: scalar base + 32-bit lane offset addressing
+    unsigned xl[NCOL]; // unsigned byte offsets from a uniform row pointer: scalar base + 32-bit lane offset addressing
 #pragma unroll
-    for (int j = 0; j < 4; j++) xl[j] = 8u * (unsigned)(minX1 + min(max(xc0 + cb + j, 0), width1 - 1));
+    for (int j = 0; j < NCOL; j++) xl[j] = 8u * (unsigned)(minX1 + min(max(xc0 + cb + j, 0), width1 - 1));
     // right pixel of (column j, slot s) is r[j - s + 2NP - 1] with r[i] = R[xr0 + i]
     const int xr0 = minX1 + xc0 + cb - d0 - (2 * NP - 1);
     unsigned xr[NR];
 #pragma unroll
     for (int i = 0; i < NR; i++) xr[i] = 8u * (unsigned)min(max(xr0 + i, 0), W - 1);
 
-    auto pix_row = [&](int row, v2s (&out)[4][NP]) {
+    auto pix_row = [&](int row, v2s (&out)[NCOL][NP]) {
         const char* L = reinterpret_cast<const char*>(Lb + (size_t)row * Wp);
         const char* R = reinterpret_cast<const char*>(Rb + (size_t)row * Wp);
         uint2 r[NR];
 #pragma unroll
         for (int i = 0; i < NR; i++) r[i] = *reinterpret_cast<const uint2*>(R + xr[i]);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NCOL; j++) {
             const uint2 l = *reinterpret_cast<const uint2*>(L + xl[j]);
             const v2s g = splat(l.x & 0xff), g0 = splat((l.x >> 8) & 0xff), g1 = splat((l.x >> 16) & 0xff);
             const v2s w = splat(l.y & 0xff), w0 = splat((l.y >> 8) & 0xff), w1 = splat((l.y >> 16) & 0xff);
@@ -210,43 +211,45 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
         }
     };
 
-    // ring of evaluated rows: slot s, dword w of thread tid at ((blk * nslot + s) * 2NP + w) * VO_COST_THREADS + tid
+    // ring of evaluated rows: slot s, dword w of thread tid at ((blk * nslot + s) * RW + w) * VO_COST_THREADS + tid
     const int nslot = 2 * SW2 + 2;
-    uint32_t* rg = ring + ((size_t)((b * 4 + stripe) * gridDim.x + blockIdx.x) * nslot) * (2 * NP * VO_COST_THREADS); // uniform
+    constexpr int RW = NCOL * NP / 2; // ring dwords per thread and slot: 4 byte costs each
+    static_assert((NCOL * NP) % 2 == 0, "the ring packs pairs of pairs");
+    uint32_t* rg = ring + ((size_t)((b * 4 + stripe) * gridDim.x + blockIdx.x) * nslot) * (RW * VO_COST_THREADS); // uniform
     const unsigned tid = threadIdx.x;
     // the first lds_slots slots of the ring live in what LDS the tile leaves free (same layout; a thread only ever
     // reads back its own dwords, so no barrier is involved); the others in global memory
     unsigned* lring = reinterpret_cast<unsigned*>(vt + 2 * CV_COLS * CS);
-    auto ring_put = [&](int slot, const v2s (&src)[4][NP]) {
-        unsigned pk[2 * NP];
+    auto ring_put = [&](int slot, const v2s (&src)[NCOL][NP]) {
+        unsigned pk[RW];
 #pragma unroll
-        for (int w = 0; w < 2 * NP; w++) { // cells (2w, 2w+1) of the thread's 4 x NP pairs, low bytes
+        for (int w = 0; w < RW; w++) { // cells (2w, 2w+1) of the thread's NCOL x NP pairs, low bytes
             const int a0 = 2 * w, a1 = 2 * w + 1;
             pk[w] = __builtin_amdgcn_perm((unsigned)as_int(src[a1 / NP][a1 % NP]), (unsigned)as_int(src[a0 / NP][a0 % NP]), 0x06040200u);
         }
         if (slot < lds_slots) {
-            unsigned* q_ = lring + slot * (2 * NP * VO_COST_THREADS);
+            unsigned* q_ = lring + slot * (RW * VO_COST_THREADS);
 #pragma unroll
-            for (int w = 0; w < 2 * NP; w++) q_[w * VO_COST_THREADS + tid] = pk[w];
+            for (int w = 0; w < RW; w++) q_[w * VO_COST_THREADS + tid] = pk[w];
         } else {
-            uint32_t* q_ = rg + (size_t)slot * (2 * NP * VO_COST_THREADS);
+            uint32_t* q_ = rg + (size_t)slot * (RW * VO_COST_THREADS);
 #pragma unroll
-            for (int w = 0; w < 2 * NP; w++) q_[w * VO_COST_THREADS + tid] = pk[w];
+            for (int w = 0; w < RW; w++) q_[w * VO_COST_THREADS + tid] = pk[w];
         }
     };
-    auto ring_get = [&](int slot, v2s (&dst)[4][NP]) {
-        unsigned pk[2 * NP];
+    auto ring_get = [&](int slot, v2s (&dst)[NCOL][NP]) {
+        unsigned pk[RW];
         if (slot < lds_slots) {
-            const unsigned* q_ = lring + slot * (2 * NP * VO_COST_THREADS);
+            const unsigned* q_ = lring + slot * (RW * VO_COST_THREADS);
 #pragma unroll
-            for (int w = 0; w < 2 * NP; w++) pk[w] = q_[w * VO_COST_THREADS + tid];
+            for (int w = 0; w < RW; w++) pk[w] = q_[w * VO_COST_THREADS + tid];
         } else {
-            const uint32_t* q_ = rg + (size_t)slot * (2 * NP * VO_COST_THREADS);
+            const uint32_t* q_ = rg + (size_t)slot * (RW * VO_COST_THREADS);
 #pragma unroll
-            for (int w = 0; w < 2 * NP; w++) pk[w] = q_[w * VO_COST_THREADS + tid];
+            for (int w = 0; w < RW; w++) pk[w] = q_[w * VO_COST_THREADS + tid];
         }
 #pragma unroll
-        for (int w = 0; w < 2 * NP; w++) {
+        for (int w = 0; w < RW; w++) {
             const int a0 = 2 * w, a1 = 2 * w + 1;
             dst[a0 / NP][a0 % NP] = as_v2s((int)__builtin_amdgcn_perm(0u, pk[w], 0x0c010c00u));
             dst[a1 / NP][a1 % NP] = as_v2s((int)__builtin_amdgcn_perm(0u, pk[w], 0x0c030c02u));
@@ -254,11 +257,13 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
     };
 
     // window rows are numbered relative to the stripe top; rows above it repeat row 0.  Row q lives in slot (q + nslot) % nslot.
-    v2s V[4][NP], t[4][NP], Lp[4][NP];
-    int m[4] = {0, 0, 0, 0};
+    v2s V[NCOL][NP], t[NCOL][NP], Lp[NCOL][NP];
+    int m[NCOL];
+#pragma unroll
+    for (int j = 0; j < NCOL; j++) m[j] = 0;
     pix_row(y0, t);
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+    for (int j = 0; j < NCOL; j++)
 #pragma unroll
         for (int k = 0; k < NP; k++) { V[j][k] = t[j][k] * (short)(SW2 + 1); Lp[j][k] = splat(0); }
     for (int q = -SW2; q <= 0; q++) ring_put((q + nslot) % nslot, t);
@@ -266,14 +271,14 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
         if (y0 + dy <= H - 1) pix_row(y0 + dy, t); // past the last image row the last row repeats: t already holds it
         ring_put(dy, t);
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < NCOL; j++)
 #pragma unroll
             for (int k = 0; k < NP; k++) V[j][k] += t[j][k];
     }
     const int inf_pk = (32767 - P1) * 0x10001;
     // tile columns that hold the first / last cost column: the horizontal window clamps there
     const int cmin = max(-xc0, 0), cmax = min(width1 - 1 - xc0, CV_COLS - 1);
-    constexpr int NC = 4 + 2 * (SWC > 0 ? SWC : 1);
+    constexpr int NC = NCOL + 2 * (SWC > 0 ? SWC : 1);
     int cidx[NC];
 #pragma unroll
     for (int i = 0; i < NC; i++) cidx[i] = min(max(cb - SWC + i, cmin), cmax) * CS + lane16;
@@ -281,9 +286,9 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
     // output addressing: uniform row pointers + a 32-bit byte offset per owned column (~0 = not stored: halo or past the row)
     char* crow = reinterpret_cast<char*>(cost + ((size_t)b * srows + si.off[stripe]) * rstride);
     char* arow = reinterpret_cast<char*>(agg + ((size_t)b * srows + si.off[stripe]) * rstride);
-    unsigned ocol[4];
+    unsigned ocol[NCOL];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < NCOL; j++) {
         const int c = cb + j, xc = xc0 + c;
         ocol[j] = (c >= SW2 && c < CV_COLS - SW2 && xc < width1) ? (unsigned)((xc * D + d0) * (int)sizeof(int16_t)) : ~0u;
     }
@@ -291,24 +296,24 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
     for (int r = 0; r < rows; r++) {
         const int y = y0 + r;
         if (r > 0) {
-            v2s gone[4][NP];
+            v2s gone[NCOL][NP];
             ring_get((r - SW2 - 1 + nslot) % nslot, gone);      // row r - SW2 - 1 leaves the window
             if (y + SW2 <= H - 1) pix_row(y + SW2, t);          // row r + SW2 enters it (the last image row repeats)
             ring_put((r + SW2) % nslot, t);
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < NCOL; j++)
 #pragma unroll
                 for (int k = 0; k < NP; k++) V[j][k] += t[j][k] - gone[j][k];
         }
         int* buf = vt + (r & 1) * (CV_COLS * CS);
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < NCOL; j++)
 #pragma unroll
             for (int k = 0; k < NP; k++) buf[(cb + j) * CS + k * 16 + lane16] = as_int(V[j][k]);
         __syncthreads(); // one barrier per row: the other buffer is rewritten only after the next barrier
-        v2s C[4][NP];
+        v2s C[NCOL][NP];
         if (SWC > 0) {
-            // compile-time window: the group's 4 windows span 4 + 2*SWC columns; every column is read once, at an
+            // compile-time window: the group's NCOL windows span NCOL + 2*SWC columns; every column is read once, at an
             // LDS offset that does not depend on the row (clamped at the ends of the cost row)
             v2s col[NC][NP];
 #pragma unroll
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
                 for (int i = 1; i <= 2 * SWC; i++) a += col[i][k];
                 C[0][k] = a;
 #pragma unroll
-                for (int j = 1; j < 4; j++) C[j][k] = C[j - 1][k] + col[j + 2 * SWC][k] - col[j - 1][k];
+                for (int j = 1; j < NCOL; j++) C[j][k] = C[j - 1][k] + col[j + 2 * SWC][k] - col[j - 1][k];
             }
         } else {
 #pragma unroll
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
                 for (int k = 0; k < NP; k++) C[0][k] += as_v2s(p[k * 16]);
             }
 #pragma unroll
-            for (int j = 1; j < 4; j++) {
+            for (int j = 1; j < NCOL; j++) {
                 const int* pa = buf + min(max(cb + j + SW2, cmin), cmax) * CS + lane16;
                 const int* ps = buf + min(max(cb + j - 1 - SW2, cmin), cmax) * CS + lane16;
 #pragma unroll
@@ -343,10 +348,10 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) m[j] = path_step<NP>(C[j], Lp[j], m[j], P1, P2, inf_pk); // four independent chains
+        for (int j = 0; j < NCOL; j++) m[j] = path_step<NP>(C[j], Lp[j], m[j], P1, P2, inf_pk); // independent chains
         if (y >= si.out0[stripe]) { // warm-up rows only feed the vertical path's state: nothing reads their C or L_top
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < NCOL; j++) {
                 if (ocol[j] != ~0u) {
                     store_pk<NP>(reinterpret_cast<int16_t*>(crow + ocol[j]), C[j]);
                     store_pk<NP>(reinterpret_cast<int16_t*>(arow + ocol[j]), Lp[j]);
@@ -625,29 +630,31 @@ int run_sgbm(vo_ctx* c)
     { StageTimer st_(c, VO_ST_VPATH);
     // the reference's window (11x11, Source/VOClass.cpp:242) gets the instantiation with a compile-time half window
     const int swc = SH2 == 5 ? 5 : 0;
+    constexpr int NCOL = vo_cost_group_cols(NP);
+    constexpr int TILE_COLS = (VO_COST_THREADS / 16) * NCOL;
     // LDS: the double-buffered tile, plus as many ring slots as fit a third of a CU's 160 KB (three blocks per CU
     // is what the kernel's register use allows at 96 disparities)
 #ifndef VO_COST_LDS_BUDGET
 #define VO_COST_LDS_BUDGET (52 * 1024)
 #endif
-    const size_t tile_bytes = (size_t)2 * CV_COLS * (16 * NP + 4) * sizeof(int);
-    const size_t slot_bytes = (size_t)2 * NP * VO_COST_THREADS * sizeof(unsigned);
+    const size_t tile_bytes = (size_t)2 * TILE_COLS * (16 * NP + 4) * sizeof(int);
+    const size_t slot_bytes = (size_t)(NCOL * NP / 2) * VO_COST_THREADS * sizeof(unsigned);
     const int lds_slots = tile_bytes >= (size_t)VO_COST_LDS_BUDGET ? 0
                         : (int)std::min<size_t>((VO_COST_LDS_BUDGET - tile_bytes) / slot_bytes, (size_t)(2 * SH2 + 2));
     const size_t lds = tile_bytes + lds_slots * slot_bytes;
-    const void* fn = swc ? reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 5>) : reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 0>);
+    const void* fn = swc ? reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 5, NCOL>) : reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 0, NCOL>);
     static bool lds_attr_set[64][2]; // per device: a kernel's attributes belong to the device's copy of the code object
     if (lds > 48 * 1024 && !lds_attr_set[c->device & 63][swc ? 1 : 0]) {
         VO_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_attr_set[c->device & 63][swc ? 1 : 0] = true;
     }
-    const int tile_out = CV_COLS - 2 * SH2;
+    const int tile_out = TILE_COLS - 2 * SH2;
     const dim3 grid((w1 + tile_out - 1) / tile_out, 4, n), blk(VO_COST_THREADS);
     if (swc)
-        hipLaunchKernelGGL((cost_vpath_kernel<NP, 5>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
+        hipLaunchKernelGGL((cost_vpath_kernel<NP, 5, NCOL>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
                            SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring, lds_slots);
     else
-        hipLaunchKernelGGL((cost_vpath_kernel<NP, 0>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
+        hipLaunchKernelGGL((cost_vpath_kernel<NP, 0, NCOL>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
                            SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring, lds_slots);
     }
     const int nseg = vo_hpath_segments(c);

@@ -130,17 +130,19 @@ int vo_fail(vo_ctx* c, int code, const char* fmt, ...);
         if (e__ != hipSuccess) return vo_fail((c), VO_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
     } while (0)
 
-// cost kernel tiling: a block of VO_COST_THREADS threads covers VO_COST_TILE_COLS cost columns (4 per 16-lane
-// group), block_size / 2 of them halo on each side
+// cost kernel tiling: a block of VO_COST_THREADS threads in lane groups of 16; a group owns vo_cost_group_cols() adjacent
+// cost columns (4; 2 once a lane holds 12 or more disparities of each), block_size / 2 columns on each side of the tile are halo
 #ifndef VO_COST_THREADS
 #define VO_COST_THREADS 256
 #endif
-constexpr int VO_COST_TILE_COLS = VO_COST_THREADS / 4;
+constexpr int vo_cost_group_cols(int pairs_per_lane) { return pairs_per_lane >= 6 ? 2 : 4; }
 inline size_t vo_cost_tiles(const vo_ctx* c)
 {
-    const int tile_out = VO_COST_TILE_COLS - 2 * (c->p.block_size / 2);
+    const int tile_out = (VO_COST_THREADS / 16) * vo_cost_group_cols(c->D / 32) - 2 * (c->p.block_size / 2);
     return (size_t)((c->width1 + tile_out - 1) / tile_out);
 }
+// dwords of the pixel-cost ring per thread and slot (4 byte costs per dword)
+inline size_t vo_cost_ring_dwords(const vo_ctx* c) { return (size_t)vo_cost_group_cols(c->D / 32) * (c->D / 32) / 2; }
 
 // horizontal paths: the left-to-right state is checkpointed every segment; a segment's columns live in registers,
 // so wide disparity ranges (more cells per lane) get shorter segments
