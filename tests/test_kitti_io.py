@@ -49,6 +49,21 @@ def test_trajectory_dump_has_six_significant_digits(tmp_path):
     assert np.allclose(kitti.read_trajectory_xyz(str(tmp_path / "t.txt")), traj, rtol=1e-5)
 
 
+def test_reference_pose_dump_round_trips_byte_for_byte(tmp_path):
+    """An excerpt of the reference's own Log/outputPoses.txt (first 200 + last 20 lines of its sequence-00 run): the
+    reader takes it and the writer reproduces the very same text, i.e. the same "x y z" layout and 6-digit printing."""
+    src = os.path.join(os.path.dirname(__file__), "golden", "reference_pose_dump_excerpt.txt")
+    text = open(src).read()
+    traj = kitti.read_trajectory_xyz(src)
+    assert traj.shape == (220, 3) and np.array_equal(traj[0], [0, 0, 0])
+    assert np.array_equal(traj[-1], [19.4278, -63.8728, 114.204])
+    kitti.write_trajectory_xyz(str(tmp_path / "again.txt"), traj)
+    assert (tmp_path / "again.txt").read_text() == text
+    # the car of that run moves 0.37 .. 1.0 m per frame over the first 200 frames
+    steps = np.linalg.norm(np.diff(traj[:200], axis=0), axis=1)
+    assert 0.36 < steps.min() and steps.max() < 1.0
+
+
 def test_png_round_trip_every_filter(tmp_path):
     rng = np.random.RandomState(3)
     img = rng.randint(0, 256, size=(37, 53)).astype(np.uint8)
