@@ -148,6 +148,37 @@ __device__ __forceinline__ void store_pk(int16_t* __restrict__ p, const v2s (&v)
     for (int k = 0; k < NP; k++) __builtin_nontemporal_store(as_int(v[k]), q + k);
 }
 
+// Buffer addressing: a uniform descriptor (base, size) in scalar registers + a 32-bit lane offset + a uniform scalar offset,
+// so the per-row address arithmetic is scalar and an offset at or past the size makes a load return 0 / drops a store.
+typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+typedef unsigned v3u32 __attribute__((ext_vector_type(3)));
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+#define VO_BUF_SKIP 0x80000000u // lane offset of a store that must not happen: past any buffer this file describes
+// NP packed pairs to byte offset `off` of the buffer, streamed (non-temporal: read back by later kernels only, and must
+// not displace the ring and the image rows in cache)
+template <int NP, int K = 0>
+__device__ __forceinline__ void store_pk_buf(__amdgpu_buffer_rsrc_t rs, unsigned off, const v2s (&v)[NP])
+{
+    constexpr int NT = 2;
+    if constexpr (NP - K >= 4) {
+        v4u32 t = {(unsigned)as_int(v[K]), (unsigned)as_int(v[K + 1]), (unsigned)as_int(v[K + 2]), (unsigned)as_int(v[K + 3])};
+        __builtin_amdgcn_raw_buffer_store_b128(t, rs, (int)off + 4 * K, 0, NT);
+        store_pk_buf<NP, K + 4>(rs, off, v);
+    } else if constexpr (NP - K == 3) {
+        v3u32 t = {(unsigned)as_int(v[K]), (unsigned)as_int(v[K + 1]), (unsigned)as_int(v[K + 2])};
+        __builtin_amdgcn_raw_buffer_store_b96(t, rs, (int)off + 4 * K, 0, NT);
+    } else if constexpr (NP - K == 2) {
+        v2u32 t = {(unsigned)as_int(v[K]), (unsigned)as_int(v[K + 1])};
+        __builtin_amdgcn_raw_buffer_store_b64(t, rs, (int)off + 4 * K, 0, NT);
+    } else if constexpr (NP - K == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)as_int(v[K]), rs, (int)off + 4 * K, 0, NT);
+    }
+}
+
 // y0: first source row a stripe walks (warm-up included), out0: first row whose results are used, off: stripe-row offset
 struct StripeInfo { int y0[4], rows[4], off[4], out0[4]; };
 
@@ -183,7 +214,7 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
     const int d0 = lane16 * 2 * NP;
     const uint2* Lb = pre + ((size_t)b * 2 + 0) * H * Wp;
     const uint2* Rb = pre + ((size_t)b * 2 + 1) * H * Wp;
-    unsigned xl[NCOL]; // unsigned byte offsets from a uniform row pointer: scalar base + 32-bit lane offset addressing
+    unsigned xl[NCOL]; // byte offsets into the frame's prefiltered image: buffer lane offsets
 #pragma unroll
     for (int j = 0; j < NCOL; j++) xl[j] = 8u * (unsigned)(minX1 + min(max(xc0 + cb + j, 0), width1 - 1));
     // right pixel of (column j, slot s) is r[j - s + 2NP - 1] with r[i] = R[xr0 + i]
@@ -192,15 +223,16 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
 #pragma unroll
     for (int i = 0; i < NR; i++) xr[i] = 8u * (unsigned)min(max(xr0 + i, 0), W - 1);
 
+    const unsigned img_bytes = (unsigned)H * (unsigned)Wp * 8u;
+    const __amdgpu_buffer_rsrc_t Lrs = make_rsrc(Lb, img_bytes), Rrs = make_rsrc(Rb, img_bytes);
     auto pix_row = [&](int row, v2s (&out)[NCOL][NP]) {
-        const char* L = reinterpret_cast<const char*>(Lb + (size_t)row * Wp);
-        const char* R = reinterpret_cast<const char*>(Rb + (size_t)row * Wp);
-        uint2 r[NR];
+        const int so = row * Wp * 8; // uniform
+        v2u32 r[NR];
 #pragma unroll
-        for (int i = 0; i < NR; i++) r[i] = *reinterpret_cast<const uint2*>(R + xr[i]);
+        for (int i = 0; i < NR; i++) r[i] = __builtin_amdgcn_raw_buffer_load_b64(Rrs, (int)xr[i], so, 0);
 #pragma unroll
         for (int j = 0; j < NCOL; j++) {
-            const uint2 l = *reinterpret_cast<const uint2*>(L + xl[j]);
+            const v2u32 l = __builtin_amdgcn_raw_buffer_load_b64(Lrs, (int)xl[j], so, 0);
             const v2s g = splat(l.x & 0xff), g0 = splat((l.x >> 8) & 0xff), g1 = splat((l.x >> 16) & 0xff);
             const v2s w = splat(l.y & 0xff), w0 = splat((l.y >> 8) & 0xff), w1 = splat((l.y >> 16) & 0xff);
 #pragma unroll
@@ -219,7 +251,9 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
     const unsigned tid = threadIdx.x;
     // the first lds_slots slots of the ring live in what LDS the tile leaves free (same layout; a thread only ever
     // reads back its own dwords, so no barrier is involved); the others in global memory
-    unsigned* lring = reinterpret_cast<unsigned*>(vt + 2 * CV_COLS * CS);
+    typedef __attribute__((address_space(3))) unsigned lds_u32;
+    lds_u32* lring = (lds_u32*)(vt + 2 * CV_COLS * CS);
+    const __amdgpu_buffer_rsrc_t grs = make_rsrc(rg, (unsigned)(nslot * RW * VO_COST_THREADS * 4));
     auto ring_put = [&](int slot, const v2s (&src)[NCOL][NP]) {
         unsigned pk[RW];
 #pragma unroll
@@ -228,25 +262,25 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
             pk[w] = __builtin_amdgcn_perm((unsigned)as_int(src[a1 / NP][a1 % NP]), (unsigned)as_int(src[a0 / NP][a0 % NP]), 0x06040200u);
         }
         if (slot < lds_slots) {
-            unsigned* q_ = lring + slot * (RW * VO_COST_THREADS);
+            lds_u32* q_ = lring + slot * (RW * VO_COST_THREADS);
 #pragma unroll
             for (int w = 0; w < RW; w++) q_[w * VO_COST_THREADS + tid] = pk[w];
         } else {
-            uint32_t* q_ = rg + (size_t)slot * (RW * VO_COST_THREADS);
 #pragma unroll
-            for (int w = 0; w < RW; w++) q_[w * VO_COST_THREADS + tid] = pk[w];
+            for (int w = 0; w < RW; w++)
+                __builtin_amdgcn_raw_buffer_store_b32(pk[w], grs, (int)(tid * 4 + w * (VO_COST_THREADS * 4)), slot * (RW * VO_COST_THREADS * 4), 0);
         }
     };
     auto ring_get = [&](int slot, v2s (&dst)[NCOL][NP]) {
         unsigned pk[RW];
         if (slot < lds_slots) {
-            const unsigned* q_ = lring + slot * (RW * VO_COST_THREADS);
+            const lds_u32* q_ = lring + slot * (RW * VO_COST_THREADS);
 #pragma unroll
             for (int w = 0; w < RW; w++) pk[w] = q_[w * VO_COST_THREADS + tid];
         } else {
-            const uint32_t* q_ = rg + (size_t)slot * (RW * VO_COST_THREADS);
 #pragma unroll
-            for (int w = 0; w < RW; w++) pk[w] = q_[w * VO_COST_THREADS + tid];
+            for (int w = 0; w < RW; w++)
+                pk[w] = __builtin_amdgcn_raw_buffer_load_b32(grs, (int)(tid * 4 + w * (VO_COST_THREADS * 4)), slot * (RW * VO_COST_THREADS * 4), 0);
         }
 #pragma unroll
         for (int w = 0; w < RW; w++) {
@@ -283,14 +317,15 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
 #pragma unroll
     for (int i = 0; i < NC; i++) cidx[i] = min(max(cb - SWC + i, cmin), cmax) * CS + lane16;
     const size_t rstride = (size_t)width1 * D;
-    // output addressing: uniform row pointers + a 32-bit byte offset per owned column (~0 = not stored: halo or past the row)
+    // output addressing: a buffer per row + a 32-bit byte offset per owned column (VO_BUF_SKIP = not stored: halo or past the row)
+    const unsigned row_bytes = (unsigned)(rstride * sizeof(int16_t));
     char* crow = reinterpret_cast<char*>(cost + ((size_t)b * srows + si.off[stripe]) * rstride);
     char* arow = reinterpret_cast<char*>(agg + ((size_t)b * srows + si.off[stripe]) * rstride);
     unsigned ocol[NCOL];
 #pragma unroll
     for (int j = 0; j < NCOL; j++) {
         const int c = cb + j, xc = xc0 + c;
-        ocol[j] = (c >= SW2 && c < CV_COLS - SW2 && xc < width1) ? (unsigned)((xc * D + d0) * (int)sizeof(int16_t)) : ~0u;
+        ocol[j] = (c >= SW2 && c < CV_COLS - SW2 && xc < width1) ? (unsigned)((xc * D + d0) * (int)sizeof(int16_t)) : VO_BUF_SKIP;
     }
 
     for (int r = 0; r < rows; r++) {
@@ -350,12 +385,11 @@ __global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2
 #pragma unroll
         for (int j = 0; j < NCOL; j++) m[j] = path_step<NP>(C[j], Lp[j], m[j], P1, P2, inf_pk); // independent chains
         if (y >= si.out0[stripe]) { // warm-up rows only feed the vertical path's state: nothing reads their C or L_top
+            const __amdgpu_buffer_rsrc_t crs = make_rsrc(crow, row_bytes), ars = make_rsrc(arow, row_bytes);
 #pragma unroll
             for (int j = 0; j < NCOL; j++) {
-                if (ocol[j] != ~0u) {
-                    store_pk<NP>(reinterpret_cast<int16_t*>(crow + ocol[j]), C[j]);
-                    store_pk<NP>(reinterpret_cast<int16_t*>(arow + ocol[j]), Lp[j]);
-                }
+                store_pk_buf<NP>(crs, ocol[j], C[j]);
+                store_pk_buf<NP>(ars, ocol[j], Lp[j]);
             }
         }
         crow += rstride * sizeof(int16_t); arow += rstride * sizeof(int16_t);
