@@ -151,6 +151,14 @@ __device__ __forceinline__ int dot2_keep(int a, int b, int c)
 __device__ __forceinline__ int from_next_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true); }
 __device__ __forceinline__ int pack_lo16(int lo, int hi) { return (int)__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
 
+// (lo >> 9, hi >> 9) as packed 16-bit halves, for |lo|, |hi| < 2^23
+__device__ __forceinline__ int pair_shr9(int lo, int hi)
+{
+    typedef short v2s16 __attribute__((ext_vector_type(2)));
+    const v2s16 t = __builtin_bit_cast(v2s16, (int)__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x06050201u));
+    return __builtin_bit_cast(int, t >> (short)1);
+}
+
 // exact sum over the 16 lanes of a group, as the float nearest to the integer (every lane gets it)
 __device__ __forceinline__ float group_sum(int v)
 {
@@ -335,12 +343,14 @@ __global__ __launch_bounds__(256) void lk_row_kernel(LkArgs a, const uint8_t* __
                         for (int k = 0; k < NR; k++) {
                             int d[NPX + 1];
 #pragma unroll
-                            for (int x = 0; x < NPX; x++) d[x] = dot2(pr[k + 1][x], w1, dot2_keep(pr[k][x], w0, C0[k][x])) >> 9;
+                            for (int x = 0; x < NPX; x++) d[x] = dot2(pr[k + 1][x], w1, dot2_keep(pr[k][x], w0, C0[k][x]));
                             d[NPX] = 0;
 #pragma unroll
                             for (int p = 0; p < NPP; p++) {
-                                // the last pair has no upper slot: its Ix/Iy halves are zero, whatever the upper 16 bits of d hold
-                                const int dp = 2 * p + 1 < NPX ? pack_lo16(d[2 * p], d[2 * p + 1]) : d[2 * p];
+                                // (d >> 9) of two slots as a 16-bit pair: |d| < 2^23, so bits 8..23 hold d >> 8 exactly and one
+                                // packed arithmetic shift finishes the job.  The last pair has no upper slot: its Ix/Iy halves
+                                // are zero, whatever the upper half holds.
+                                const int dp = pair_shr9(d[2 * p], d[2 * p + 1]);
                                 sb1 = dot2(dp, IxP[k][p], sb1); sb2 = dot2(dp, IyP[k][p], sb2);
                             }
                         }
