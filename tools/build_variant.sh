@@ -4,7 +4,7 @@
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
-src=$root/visualodometry_amd/csrc
+src=${VO_SRC:-$root/visualodometry_amd/csrc}
 out=$root/gpurun_variants
 mkdir -p $out/obj_$name
 for f in vo_abi fast sgbm lk pnp; do
