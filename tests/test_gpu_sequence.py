@@ -97,3 +97,15 @@ def test_depth_point_cloud_export(frames5, tmp_path):
     r, c, z = lines[10].split()[:3]
     assert float(z) == pytest.approx(-depth[int(r), int(c)], rel=1e-5)
     ctx.close()
+
+
+def test_chunk_of_a_sequence_equals_the_slice_of_the_whole(frames5):
+    """chunked sharding: steps 1..2 computed alone are the same [R|t] as steps 1..2 of the whole sequence"""
+    seq, frames = frames5
+    ctx = abi.Context(abi.default_params(W, H, max_batch=4, **PARAMS))
+    ctx.set_calib(seq.P0, seq.P1)
+    whole, _ = sequence.run_sequence(ctx, frames)
+    part, info = sequence.run_chunk(ctx, frames, 1, 3)
+    assert part.shape == (2, 4, 4) and len(info) == 2
+    assert np.array_equal(part, whole[1:3])
+    ctx.close()

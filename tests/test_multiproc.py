@@ -41,6 +41,21 @@ def worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def chunk_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    owner = sequence.assign_chunks(LENGTHS, world)
+    local = {}
+    for i, first, end in owner[rank]:
+        local[i] = (first, fake_sequence_Rts(i, LENGTHS[i] - 1)[first:end])   # the slice this rank would have computed
+    allr = sequence.gather_trajectories(local, len(LENGTHS), max(LENGTHS) - 1)
+    finals = {i: sequence.integrate(allr[i].reshape(-1, 4, 4))[0][-1].tolist() for i in sorted(allr)}
+    q.put((rank, owner, finals))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -75,3 +90,44 @@ def test_gather_single_process_is_identity():
     local = {0: fake_sequence_Rts(0, 5), 2: fake_sequence_Rts(2, 3)}
     out = sequence.gather_trajectories(local, 3, 8)
     assert sorted(out) == [0, 2] and np.array_equal(out[0], local[0]) and np.array_equal(out[2], local[2])
+
+
+def test_chunk_assignment_is_a_balanced_partition():
+    for world in (1, 2, 3, 8):
+        owner = sequence.assign_chunks(LENGTHS, world)
+        seen = {}
+        for r, chunks in enumerate(owner):
+            for i, first, end in chunks:
+                assert 0 <= first < end <= LENGTHS[i] - 1
+                for k in range(first, end):
+                    assert (i, k) not in seen
+                    seen[(i, k)] = r
+        total = sum(n - 1 for n in LENGTHS)
+        assert len(seen) == total
+        loads = [sum(e - f for _, f, e in chunks) for chunks in owner]
+        assert max(loads) - min(loads) <= 1
+    # KITTI odometry lengths on 8 ranks: whole sequences are bounded by the longest one, chunks are not
+    kitti = [4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201]
+    whole = sequence.assign_sequences(kitti, 8)
+    assert max(sum(kitti[i] - 1 for i in o) for o in whole) == 4660
+    chunks = sequence.assign_chunks(kitti, 8)
+    assert max(sum(e - f for _, f, e in c) for c in chunks) == -(-(sum(kitti) - len(kitti)) // 8)
+
+
+def test_chunk_sharding_and_gather_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=chunk_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    owner = sorted(res)[0][1]
+    assert any(i == j for i, _, _ in owner[0] for j, _, _ in owner[1])   # one sequence is split between the ranks
+    want = {i: sequence.integrate(fake_sequence_Rts(i, LENGTHS[i] - 1).reshape(-1, 4, 4))[0][-1].tolist() for i in range(len(LENGTHS))}
+    for rank, _, finals in res:
+        assert finals == want, rank

@@ -27,6 +27,33 @@ def assign_sequences(lengths, world_size):
     return owner
 
 
+def assign_chunks(lengths, world_size):
+    """Chunked sharding: the steps of all sequences, laid end to end, are cut into world_size contiguous ranges of
+    (almost) equal size.  Returns per rank a list of (sequence index, first step, end step) with end exclusive; step k
+    of a sequence is the frame pair (k, k + 1).  Unlike whole-sequence sharding the makespan is not bounded below by
+    the longest sequence; the per-step [R|t] are position-independent, so the ordered product over the gathered
+    steps is the same as a serial run's."""
+    steps = [max(n - 1, 0) for n in lengths]
+    total = sum(steps)
+    owner = [[] for _ in range(world_size)]
+    start = 0  # global index of the current sequence's step 0
+    for i, n in enumerate(steps):
+        for r in range(world_size):
+            lo = max(r * total // world_size, start)
+            hi = min((r + 1) * total // world_size, start + n)
+            if hi > lo:
+                owner[r].append((i, lo - start, hi - start))
+        start += n
+    return owner
+
+
+def run_chunk(ctx, frames, first, end, batch=None):
+    """Steps first..end-1 of a sequence (frame pairs (k, k+1)): frames[first..end] are read.  Same results as the
+    corresponding slice of run_sequence()."""
+    Rt, info = run_sequence(ctx, frames[first:end + 1], batch)
+    return Rt, info
+
+
 def integrate(Rts, pose0=None):
     """Ordered product pose_k = pose_{k-1} * inv(Rt_k); returns (k+1) x 3 translations starting at pose0's."""
     pose = np.eye(4) if pose0 is None else np.array(pose0, dtype=np.float64)
@@ -61,16 +88,18 @@ def run_sequence(ctx, frames, batch=None):
 
 
 def gather_trajectories(local, n_sequences, max_steps, group=None):
-    """local: {sequence index: [steps, 16] relative Rt}.  One all_gather of fixed-size padded buffers;
-    returns {sequence index: [steps, 16]} for all sequences on every rank."""
+    """local: {sequence index: [steps, 16] relative Rt}, or {sequence index: (first step, [steps, 16])} for a rank that
+    holds a chunk of a sequence (several ranks may then hold disjoint chunks of one sequence).  One all_gather of
+    fixed-size padded buffers; returns {sequence index: [steps, 16]} for all sequences on every rank."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     buf = torch.zeros((n_sequences, max_steps, 16), dtype=torch.float64)
     cnt = torch.zeros((n_sequences,), dtype=torch.int64)
     for i, Rt in local.items():
+        first, Rt = Rt if isinstance(Rt, tuple) else (0, Rt)
         a = np.asarray(Rt, dtype=np.float64).reshape(-1, 16)
-        buf[i, :a.shape[0]] = torch.from_numpy(a)
+        buf[i, first:first + a.shape[0]] = torch.from_numpy(a)
         cnt[i] = a.shape[0]
     if world > 1:
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
@@ -79,6 +108,6 @@ def gather_trajectories(local, n_sequences, max_steps, group=None):
         cnts = [torch.empty_like(cnt) for _ in range(world)]
         dist.all_gather(bufs, buf, group=group)
         dist.all_gather(cnts, cnt, group=group)
-        buf = torch.stack(bufs).sum(0).cpu()   # every sequence is owned by exactly one rank; the others hold zeros
+        buf = torch.stack(bufs).sum(0).cpu()   # every step is owned by exactly one rank; the others hold zeros there
         cnt = torch.stack(cnts).sum(0).cpu()
     return {i: buf[i, :int(cnt[i])].numpy().copy() for i in range(n_sequences) if int(cnt[i]) > 0}
