@@ -96,9 +96,19 @@ def cpu_baseline(frames, seq, shape, sample_pairs):
         i = k % nd
         ob.step(frames[i][0], frames[i][1], frames[i + 1][0], frames[i + 1][1], p, seq.P0, seq.P1, pose)
     dt = time.perf_counter() - t0
+    # the same port on one thread, on a smaller sample
+    ob.set_threads(1)
+    n1 = max(1, min(3, npairs))
+    t1 = time.perf_counter()
+    for k in range(n1):
+        i = k % nd
+        ob.step(frames[i][0], frames[i][1], frames[i + 1][0], frames[i + 1][1], p, seq.P0, seq.P1, pose)
+    dt1 = time.perf_counter() - t1
+    ob.set_threads(threads)
     return {"value": npairs / dt, "unit": "stereo frames/s", "cores": threads, "kind": "port",
             "sample": "%d frame pairs of the same synthetic %dx%d sequence, %.1f s wall (SGBM on 4 stripe threads, LK on %d)" %
-                      (npairs, shape["width"], shape["height"], dt, threads)}
+                      (npairs, shape["width"], shape["height"], dt, threads),
+            "single_thread_value": n1 / dt1, "single_thread_sample": "%d frame pairs, %.1f s wall" % (n1, dt1)}
 
 
 def main():
@@ -235,6 +245,16 @@ def main():
         for _ in range(3):
             ctx.step()
         isolated = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in ctx.timing().items()}
+    # latency of one frame pair alone (batch of 1, one stream, nothing else in flight), outside the timed region
+    latency_ms = None
+    if args.mode == "pairs":
+        ctx.set_images_device(1, [t.data_ptr() for t in (lt1, rt1, lt2, rt2)], W, W * H, keep=(lt1, rt1, lt2, rt2))
+        for _ in range(2):
+            ctx.step()
+        tl = time.perf_counter()
+        for _ in range(10):
+            ctx.step()
+        latency_ms = (time.perf_counter() - tl) / 10 * 1e3
     if rank == 0:
         steps = args.steps
         fps = world * B * steps / dt
@@ -269,7 +289,7 @@ def main():
             "config": {"workload": "%s-shape synthetic stereo, %dx%d, %d disparities, %d frame pairs per step per GPU, whole hot path "
                                    "(SGBM-3way + FAST + circular KLT + triangulation + PnP-RANSAC)" % (args.workload, W, H, D, B),
                        "batch": B, "batches_in_flight": nctx, "input_mode": args.mode, "sharding": "independent sequences, one per GPU; poses all-gathered once (RCCL)",
-                       "mpix_per_s": fps * W * H / 1e6,
+                       "mpix_per_s": fps * W * H / 1e6, "latency_ms_one_pair_alone": latency_ms,
                        "features_per_frame": int(np.mean([i.n_features for i in info])),
                        "matches_per_frame": int(np.mean([i.n_matched for i in info])),
                        "stage_ms_timed_region": {k: round(v, 4) for k, v in stage_ms.items()},
@@ -277,6 +297,8 @@ def main():
                        "whole_path_algorithmic_GBs": frame_bytes(W, H, D) * fps / world / 1e9},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         # what plain streaming kernels reach on this GPU (tools/micro/hbm_rate.hip, measured once)
+                         "streaming_GBs_measured": {"read": 6290, "write": 3890, "copy": 4450, "1_read_4_writes": 4440},
                          "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": excl.get(dom, 0.0),
                          "avg_launch_ms_timed_region": stage_ms.get(dom, 0.0), "frac_timed_region": frac(stage_ms, dom),
                          "measured": "HIP events on the kernel's stream, one batch in flight, right after the timed region"
