@@ -35,16 +35,26 @@ struct LevelArgs { int w, h, pitch, rows; unsigned img_off, der_off; };
 // (LT1, RT1, LT2, RT2); 2 for consecutive frames of a sequence, where (b, LT2) is the same image as (b + 1, LT1).
 struct PyrArgs { int nlevels, border, img_per_b; LevelArgs lv[VO_MAX_LEVELS]; unsigned long long pyr_bytes, der_elems; };
 
+// Thread layout of the per-pixel kernels below: a block is 64 threads wide x 4 rows, a thread owns 4 adjacent pixels of a
+// row (levels are stored with a pitch that is a multiple of 16, so that is one aligned dword of the level).
+constexpr int PX_T = 64, PX_R = 4, PX_N = 4;
+
 __global__ __launch_bounds__(256) void level0_kernel(const uint8_t* i0, const uint8_t* i1, const uint8_t* i2, const uint8_t* i3,
                                                      size_t pitch, size_t fstride, PyrArgs pa, uint8_t* __restrict__ pyr)
 {
-    const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y;
+    const int px0 = (blockIdx.x * PX_T + (threadIdx.x & (PX_T - 1))) * PX_N, py = blockIdx.y * PX_R + (threadIdx.x / PX_T);
     const int b = blockIdx.z / pa.img_per_b, which = blockIdx.z % pa.img_per_b;
     const LevelArgs L = pa.lv[0];
-    if (px >= L.pitch) return;
+    if (px0 >= L.pitch || py >= L.rows) return;
     const uint8_t* src = (which == 0 ? i0 : which == 1 ? i1 : which == 2 ? i2 : i3) + (size_t)b * fstride;
-    int x = reflect101(min(px, L.w + 2 * pa.border - 1) - pa.border, L.w), y = reflect101(py - pa.border, L.h);
-    pyr[(size_t)blockIdx.z * pa.pyr_bytes + L.img_off + (size_t)py * L.pitch + px] = src[(size_t)y * pitch + x];
+    const uint8_t* row = src + (size_t)reflect101(py - pa.border, L.h) * pitch;
+    unsigned v = 0;
+#pragma unroll
+    for (int j = 0; j < PX_N; j++) {
+        const int x = reflect101(min(px0 + j, L.w + 2 * pa.border - 1) - pa.border, L.w);
+        v |= (unsigned)row[x] << (8 * j);
+    }
+    *reinterpret_cast<unsigned*>(pyr + (size_t)blockIdx.z * pa.pyr_bytes + L.img_off + (size_t)py * L.pitch + px0) = v;
 }
 
 constexpr int PD_TX = 32, PD_TY = 8;
@@ -90,21 +100,38 @@ __global__ __launch_bounds__(256) void border_kernel(PyrArgs pa, int level, uint
 __global__ __launch_bounds__(256) void scharr_kernel(PyrArgs pa, int level, const uint8_t* __restrict__ pyr, int16_t* __restrict__ der)
 {
     const LevelArgs L = pa.lv[level];
-    const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y;
-    if (px >= L.pitch) return;
-    const int x = px - pa.border, y = py - pa.border;
-    int ix = 0, iy = 0;
-    if (x >= 0 && x < L.w && y >= 0 && y < L.h) {
-        const uint8_t* p = pyr + (size_t)blockIdx.z * pa.pyr_bytes + L.img_off + (size_t)py * L.pitch + px;
+    const int px0 = (blockIdx.x * PX_T + (threadIdx.x & (PX_T - 1))) * PX_N, py = blockIdx.y * PX_R + (threadIdx.x / PX_T);
+    if (px0 >= L.pitch || py >= L.rows) return;
+    const int y = py - pa.border;
+    int4 o = make_int4(0, 0, 0, 0);
+    // any of the 4 pixels inside the image?  (then rows py-1, py+1 and columns px0-1 .. px0+4 lie in the bordered level)
+    if (y >= 0 && y < L.h && px0 + PX_N - 1 >= pa.border && px0 < pa.border + L.w) {
+        const uint8_t* p = pyr + (size_t)blockIdx.z * pa.pyr_bytes + L.img_off + (size_t)py * L.pitch + px0;
         const int P = L.pitch;
-        int a00 = p[-P - 1], a01 = p[-P], a02 = p[-P + 1];
-        int a10 = p[-1], a12 = p[1];
-        int a20 = p[P - 1], a21 = p[P], a22 = p[P + 1];
-        ix = ((a02 + a22) * 3 + a12 * 10) - ((a00 + a20) * 3 + a10 * 10);
-        iy = ((a20 - a00) + (a22 - a02)) * 3 + (a21 - a01) * 10;
+        int c[3][PX_N + 2]; // columns px0-1 .. px0+4 of rows py-1, py, py+1
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const uint8_t* q = p + (r - 1) * P;
+            const unsigned cur = *reinterpret_cast<const unsigned*>(q);
+            const unsigned prv = px0 >= PX_N ? *reinterpret_cast<const unsigned*>(q - 4) : 0u;
+            const unsigned nxt = px0 + PX_N < L.pitch ? *reinterpret_cast<const unsigned*>(q + 4) : 0u;
+            c[r][0] = prv >> 24;
+#pragma unroll
+            for (int j = 0; j < PX_N; j++) c[r][1 + j] = (cur >> (8 * j)) & 0xff;
+            c[r][PX_N + 1] = nxt & 0xff;
+        }
+        int v[PX_N];
+#pragma unroll
+        for (int j = 0; j < PX_N; j++) {
+            const int x = px0 + j - pa.border;
+            const int ix = ((c[0][j + 2] + c[2][j + 2]) * 3 + c[1][j + 2] * 10) - ((c[0][j] + c[2][j]) * 3 + c[1][j] * 10);
+            const int iy = ((c[2][j] - c[0][j]) + (c[2][j + 2] - c[0][j + 2])) * 3 + (c[2][j + 1] - c[0][j + 1]) * 10;
+            v[j] = (x >= 0 && x < L.w) ? ((ix & 0xffff) | (iy << 16)) : 0;
+        }
+        o = make_int4(v[0], v[1], v[2], v[3]);
     }
     int* out = reinterpret_cast<int*>(der + (size_t)blockIdx.z * pa.der_elems + L.der_off);
-    out[(size_t)py * L.pitch + px] = (ix & 0xffff) | (iy << 16);
+    *reinterpret_cast<int4*>(out + (size_t)py * L.pitch + px0) = o;
 }
 
 #define DPP_ADD(v, ctrl) ((v) + __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, false))
@@ -456,7 +483,8 @@ int launch_pyramids(vo_ctx* c)
     StageTimer st_(c, VO_ST_PYRAMID);
     const PyrArgs pa = make_pyr_args(c);
     const int nimg = c->seq_mode ? 2 * (c->n + 1) : 4 * c->n;
-    hipLaunchKernelGGL(level0_kernel, dim3((pa.lv[0].pitch + 255) / 256, pa.lv[0].rows, nimg), dim3(256), 0, c->stream,
+    auto px_grid = [&](int l) { return dim3((pa.lv[l].pitch / PX_N + PX_T - 1) / PX_T, (pa.lv[l].rows + PX_R - 1) / PX_R, nimg); };
+    hipLaunchKernelGGL(level0_kernel, px_grid(0), dim3(256), 0, c->stream,
                        c->img[0], c->img[1], c->img[2], c->img[3], c->pitch, c->fstride, pa, c->pyr);
     for (int l = 1; l <= c->nlevels; l++) {
         hipLaunchKernelGGL(pyrdown_kernel, dim3((pa.lv[l].w + PD_TX - 1) / PD_TX, (pa.lv[l].h + PD_TY - 1) / PD_TY, nimg), dim3(256), 0,
@@ -464,7 +492,7 @@ int launch_pyramids(vo_ctx* c)
         hipLaunchKernelGGL(border_kernel, dim3((pa.lv[l].pitch + 255) / 256, pa.lv[l].rows, nimg), dim3(256), 0, c->stream, pa, l, c->pyr);
     }
     for (int l = 0; l <= c->nlevels; l++)
-        hipLaunchKernelGGL(scharr_kernel, dim3((pa.lv[l].pitch + 255) / 256, pa.lv[l].rows, nimg), dim3(256), 0, c->stream, pa, l, c->pyr, c->der);
+        hipLaunchKernelGGL(scharr_kernel, px_grid(l), dim3(256), 0, c->stream, pa, l, c->pyr, c->der);
     VO_HIP(c, hipGetLastError());
     return VO_OK;
 }

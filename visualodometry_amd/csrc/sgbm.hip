@@ -47,40 +47,52 @@ __device__ __forceinline__ int row_from_prev(int v, int edge) { return __builtin
 __device__ __forceinline__ int row_from_next(int v, int edge) { return __builtin_amdgcn_update_dpp(edge, v, 0x101, 0xF, 0xF, false); }
 
 // ---------------------------------------------------------------- prefilter
-__device__ __forceinline__ int grad_clip(const uint8_t* __restrict__ img, size_t pitch, int W, int H, int x, int y, int ftzero)
-{
-    if (x <= 0 || x >= W - 1) return ftzero;
-    const uint8_t* r = img + (size_t)y * pitch;
-    const uint8_t* rn = y > 0 ? r - pitch : r;
-    const uint8_t* rs = y < H - 1 ? r + pitch : r;
-    int v = (r[x + 1] - r[x - 1]) * 2 + rn[x + 1] - rn[x - 1] + rs[x + 1] - rs[x - 1];
-    return min(max(v, -ftzero), ftzero) + ftzero;
-}
-__device__ __forceinline__ int raw_val(const uint8_t* __restrict__ img, size_t pitch, int W, int x, int y, int ftzero)
-{
-    if (x <= 0 || x >= W - 1) return ftzero;
-    return img[(size_t)y * pitch + x];
-}
-
+// A block is 64 threads wide x 4 rows, a thread owns 4 adjacent pixels: it reads columns x0-2 .. x0+5 of three rows once
+// and writes 32 contiguous bytes.  Border rule of the original: the clipped gradient and the raw value of the first and
+// the last column are the constant ftzero; half-pixel values are averages with the horizontal neighbours.
+constexpr int PF_T = 64, PF_R = 4, PF_N = 4;
 __global__ __launch_bounds__(256) void prefilter_kernel(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                         size_t pitch, size_t fstride, int W, int H, int Wp, int ftzero,
-                                                        uint2* __restrict__ pre)
+                                                        uint4* __restrict__ pre)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int x0 = (blockIdx.x * PF_T + (threadIdx.x & (PF_T - 1))) * PF_N, y = blockIdx.y * PF_R + (threadIdx.x / PF_T);
     const int b = blockIdx.z >> 1, which = blockIdx.z & 1;
-    if (x >= W) return;
+    if (x0 >= W || y >= H) return;
     const uint8_t* img = (which ? right : left) + (size_t)b * fstride;
-    int g = grad_clip(img, pitch, W, H, x, y, ftzero);
-    int r = raw_val(img, pitch, W, x, y, ftzero);
-    int gl = g, gr = g, rl = r, rr = r;
-    if (x > 0) { gl = (g + grad_clip(img, pitch, W, H, x - 1, y, ftzero)) >> 1; rl = (r + raw_val(img, pitch, W, x - 1, y, ftzero)) >> 1; }
-    if (x < W - 1) { gr = (g + grad_clip(img, pitch, W, H, x + 1, y, ftzero)) >> 1; rr = (r + raw_val(img, pitch, W, x + 1, y, ftzero)) >> 1; }
-    unsigned g0 = min(min(gl, gr), g), g1 = max(max(gl, gr), g);
-    unsigned r0 = min(min(rl, rr), r), r1 = max(max(rl, rr), r);
-    uint2 o;
-    o.x = (unsigned)g | (g0 << 8) | (g1 << 16);
-    o.y = (unsigned)r | (r0 << 8) | (r1 << 16);
-    pre[(((size_t)b * 2 + which) * H + y) * Wp + x] = o;
+    const uint8_t* r1 = img + (size_t)y * pitch;
+    const uint8_t* r0 = y > 0 ? r1 - pitch : r1;
+    const uint8_t* r2 = y < H - 1 ? r1 + pitch : r1;
+    int a0[PF_N + 4], a1[PF_N + 4], a2[PF_N + 4]; // columns x0-2 .. x0+5; a clamped column is never used (border rule)
+#pragma unroll
+    for (int i = 0; i < PF_N + 4; i++) {
+        const int xc = min(max(x0 - 2 + i, 0), W - 1);
+        a0[i] = r0[xc]; a1[i] = r1[xc]; a2[i] = r2[xc];
+    }
+    int g[PF_N + 2], r[PF_N + 2]; // columns x0-1 .. x0+4
+#pragma unroll
+    for (int k = 0; k < PF_N + 2; k++) {
+        const int i = k + 1, x = x0 - 1 + k;
+        const int v = (a1[i + 1] - a1[i - 1]) * 2 + a0[i + 1] - a0[i - 1] + a2[i + 1] - a2[i - 1];
+        const bool edge = x <= 0 || x >= W - 1;
+        g[k] = edge ? ftzero : min(max(v, -ftzero), ftzero) + ftzero;
+        r[k] = edge ? ftzero : a1[i];
+    }
+    unsigned o[2 * PF_N];
+#pragma unroll
+    for (int j = 0; j < PF_N; j++) {
+        const int k = j + 1, x = x0 + j;
+        int gl = g[k], gr = g[k], rl = r[k], rr = r[k];
+        if (x > 0) { gl = (g[k] + g[k - 1]) >> 1; rl = (r[k] + r[k - 1]) >> 1; }
+        if (x < W - 1) { gr = (g[k] + g[k + 1]) >> 1; rr = (r[k] + r[k + 1]) >> 1; }
+        const unsigned g0 = min(min(gl, gr), g[k]), g1 = max(max(gl, gr), g[k]);
+        const unsigned q0 = min(min(rl, rr), r[k]), q1 = max(max(rl, rr), r[k]);
+        o[2 * j] = (unsigned)g[k] | (g0 << 8) | (g1 << 16);
+        o[2 * j + 1] = (unsigned)r[k] | (q0 << 8) | (q1 << 16);
+    }
+    // Wp is W rounded up to 4 pixels: the (at most 3) pixels past W of the last thread land in the row's padding
+    uint4* dst = pre + ((((size_t)b * 2 + which) * H + y) * Wp + x0) / 2;
+    dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
 // ---------------------------------------------------------------- pixel cost + horizontal window
@@ -654,12 +666,12 @@ template <int NP>
 int run_sgbm(vo_ctx* c)
 {
     const int W = c->W, H = c->H, D = c->D, w1 = c->width1, n = c->n, SH2 = c->p.block_size / 2;
-    const int Wp = W;
+    const int Wp = vo_pre_pitch(c);
     StripeInfo si;
     for (int s = 0; s < 4; s++) { si.y0[s] = c->stripe_y0[s]; si.rows[s] = c->stripe_rows[s]; si.off[s] = c->stripe_row_off[s]; si.out0[s] = std::min(s * c->stripe_sz, H); }
     { StageTimer st_(c, VO_ST_PREFILTER);
-    hipLaunchKernelGGL(prefilter_kernel, dim3((W + 255) / 256, H, 2 * n), dim3(256), 0, c->stream, c->img[0], c->img[1], c->pitch,
-                       c->fstride, W, H, Wp, c->ftzero, reinterpret_cast<uint2*>(c->pre));
+    hipLaunchKernelGGL(prefilter_kernel, dim3(((W + PF_N - 1) / PF_N + PF_T - 1) / PF_T, (H + PF_R - 1) / PF_R, 2 * n), dim3(256), 0, c->stream,
+                       c->img[0], c->img[1], c->pitch, c->fstride, W, H, Wp, c->ftzero, reinterpret_cast<uint4*>(c->pre));
     }
     { StageTimer st_(c, VO_ST_VPATH);
     // the reference's window (11x11, Source/VOClass.cpp:242) gets the instantiation with a compile-time half window

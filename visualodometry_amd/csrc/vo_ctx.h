@@ -55,7 +55,7 @@ struct vo_ctx {
     bool seq_mode = false;
 
     // ---- SGBM ----
-    uint8_t* pre = nullptr;      // prefiltered rows: [n][2 images][H][Wp] x 8 bytes (g,g0,g1,r,r0,r1,0,0)
+    uint8_t* pre = nullptr;      // prefiltered rows: [n][2 images][H][vo_pre_pitch] x 8 bytes (g,g0,g1,0,r,r0,r1,0)
     uint32_t* ring = nullptr;    // pixel-cost rows in flight of the cost kernel: [n][4 stripes][x tiles][block_size + 1][D / 16][256]
     int16_t* cost = nullptr;     // [n][srows][width1][D]
     int16_t* agg = nullptr;      // [n][srows][width1][D]  L_top, then L_top + L_lr
@@ -146,6 +146,8 @@ inline size_t vo_cost_ring_dwords(const vo_ctx* c) { return (size_t)vo_cost_grou
 
 // horizontal paths: the left-to-right state is checkpointed every segment; a segment's columns live in registers,
 // so wide disparity ranges (more cells per lane) get shorter segments
+// pixels per row of the prefiltered images: the width rounded up to the 4 pixels a prefilter thread writes
+inline int vo_pre_pitch(const vo_ctx* c) { return (c->W + 3) & ~3; }
 constexpr int vo_hpath_seg(int pairs_per_lane) { return pairs_per_lane <= 4 ? 16 : 8; }
 inline int vo_hpath_segments(const vo_ctx* c) { const int seg = vo_hpath_seg(c->D / 32); return (c->width1 + seg - 1) / seg; }
 
