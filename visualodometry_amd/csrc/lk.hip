@@ -141,6 +141,7 @@ __device__ __forceinline__ int cv_round(float v) { return __float2int_rn(v); }
 struct LkArgs {
     PyrArgs pa;
     int win, max_count, max_features;
+    int groups_per_frame, n_frames; // 16-feature groups a frame is given blocks for; frames in the batch
     float min_eig;
     double eps2;
 };
@@ -257,10 +258,16 @@ __global__ __launch_bounds__(256) void lk_row_kernel(LkArgs a, const uint8_t* __
     constexpr int NPX = 4 * NDW - 1;   // pixel slots per window row (win <= NPX)
     constexpr int NPP = 2 * NDW;       // slot pairs per window row
     const int lane16 = threadIdx.x & 15;
-    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int b = blockIdx.y;
+    // Blocks are dealt round-robin over the 8 XCDs, each with its own L2.  Block id -> (frame, feature group) is chosen
+    // so that one XCD walks a contiguous run of feature groups: neighbouring features (row-major order) read
+    // overlapping window rows of the same pyramids, and a frame's pyramids are then cached by one L2, not by eight.
+    const int per_xcd = (a.groups_per_frame * a.n_frames + 7) / 8;
+    const int gid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (gid >= a.groups_per_frame * a.n_frames) return;
+    const int b = gid / a.groups_per_frame, fgroup = gid % a.groups_per_frame;
+    const int i = fgroup * 16 + (threadIdx.x >> 4);
     const int nf = n_feat[b];
-    if (blockIdx.x * 16 + (int)(threadIdx.x >> 6) * 4 >= nf) return; // uniform per wavefront
+    if (fgroup * 16 + (int)(threadIdx.x >> 6) * 4 >= nf) return; // uniform per wavefront
     const bool have = i < nf;
     const int win = a.win;
     const float half = (win - 1) * 0.5f;
@@ -512,7 +519,8 @@ int launch_match_klt(vo_ctx* c, bool counts_on_host)
     if (counts_on_host) for (int b = 0; b < c->n; b++) nmax = std::max(nmax, c->h_nfeat[b]);
     if (nmax > 0) {
         StageTimer st_(c, VO_ST_LK);
-        dim3 g16((nmax + 15) / 16, c->n), blk16(256);
+        a.groups_per_frame = (nmax + 15) / 16; a.n_frames = c->n;
+        dim3 g16(8 * ((a.groups_per_frame * c->n + 7) / 8)), blk16(256);
         if (a.win <= 15) hipLaunchKernelGGL((lk_row_kernel<1, 4>), g16, blk16, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
         else if (a.win <= 23) hipLaunchKernelGGL((lk_row_kernel<2, 6>), g16, blk16, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
         else hipLaunchKernelGGL((lk_row_kernel<2, 8>), g16, blk16, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
