@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--inflight", type=int, default=3, help="contexts taking turns (overlaps host PnP with GPU work)")
+    ap.add_argument("--latency", action="store_true",
+                    help="also time one frame pair alone (batch of 1) after the run; off by default so that a kernel profile "
+                         "of the default command holds launches of one batch size only")
     ap.add_argument("--mode", default="pairs", choices=["pairs", "sequence"],
                     help="pairs: B independent frame pairs, 4 pyramids each (what the reference rebuilds per step); "
                          "sequence: B + 1 consecutive frames, every frame pyramided once")
@@ -247,7 +250,7 @@ def main():
         isolated = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in ctx.timing().items()}
     # latency of one frame pair alone (batch of 1, one stream, nothing else in flight), outside the timed region
     latency_ms = None
-    if args.mode == "pairs":
+    if args.latency and args.mode == "pairs":
         ctx.set_images_device(1, [t.data_ptr() for t in (lt1, rt1, lt2, rt2)], W, W * H, keep=(lt1, rt1, lt2, rt2))
         for _ in range(2):
             ctx.step()
