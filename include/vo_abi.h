@@ -42,7 +42,8 @@ typedef enum {
     VO_ERR_NO_DEVICE = -4,
     VO_ERR_STATE = -5,        /* stage called before the stage that produces its input */
     VO_ERR_CAPACITY = -6,     /* more features than max_features; results were truncated */
-    VO_ERR_NOT_ENOUGH_POINTS = -7, /* fewer than 4 3D-2D correspondences (OpenCV would throw) */
+    VO_ERR_NOT_ENOUGH_POINTS = -7, /* a frame has fewer than 5 3D-2D correspondences (OpenCV throws below 4; the 4-point
+                                    * minimal solver is not provided).  In a batch the other frames are complete: see vo_step */
     VO_ERR_UNSUPPORTED = -8
 } vo_status;
 
@@ -172,7 +173,10 @@ int vo_estimate_motion(vo_ctx* ctx, double* Rt_out, vo_frame_info* info /* nulla
 int vo_integrate_pose(double pose_inout[16], const double Rt[16]);
 
 /* One iteration of Source/main.cpp:36-60 for n frame pairs, images already set:
- * disparity, FAST, circular KLT, triangulation, PnP.  Same results as the stage calls in sequence. */
+ * disparity, FAST, circular KLT, triangulation, PnP.  Same results as the stage calls in sequence.
+ * Frames of a batch are independent.  If some frames end with too few correspondences the call returns
+ * VO_ERR_NOT_ENOUGH_POINTS, but Rt_out and info are filled for every frame: the frames that failed have ok = 0 and the
+ * identity as [R|t], all others hold their results. */
 int vo_step(vo_ctx* ctx, double* Rt_out /* n*16 */, vo_frame_info* info /* nullable, n */);
 /* The same step in two halves, so that a caller with two contexts can overlap the host part (minimal
  * solvers, final refine) of one batch with the GPU part of the next: vo_step_submit enqueues every GPU

@@ -89,3 +89,39 @@ def test_stages_against_oracle(cfg):
         assert np.abs(Rt[0][:3, 3] - want[:3, 3]).max() <= 1e-3
         assert np.abs(Rt[0][:3, :3] - want[:3, :3]).max() <= 1e-4
     ctx.close()
+
+
+def test_batch_with_a_textureless_pair_in_the_middle():
+    """frames of a batch are independent: a pair without any corner (no features, no pose) between two ordinary pairs
+    leaves their results untouched and is itself reported like the oracle reports it"""
+    W, H = 320, 96
+    seq = synth.Sequence(seed=1234, width=W, height=H)
+    f = [seq.frame(i) for i in range(3)]
+    flat = np.full((H, W), 77, dtype=np.uint8)
+    lt1 = np.stack([f[0][0], flat, f[1][0]]); rt1 = np.stack([f[0][1], flat, f[1][1]])
+    lt2 = np.stack([f[1][0], flat, f[2][0]]); rt2 = np.stack([f[1][1], flat, f[2][1]])
+    p = abi.default_params(W, H, max_batch=3, num_disparities=64, max_features=4096)
+    ctx = abi.Context(p)
+    ctx.set_calib(seq.P0, seq.P1)
+    ctx.set_images(lt1, rt1, lt2, rt2)
+    with pytest.raises(abi.VoError) as e:
+        ctx.step()
+    assert e.value.code == -7
+    Rt, info = ctx.step(strict=False)
+    assert np.array_equal(Rt[1], np.eye(4))
+    op = oracle_params(p)
+    for b in range(3):
+        want, oinfo = ob.step(lt1[b], rt1[b], lt2[b], rt2[b], op, seq.P0, seq.P1, np.eye(4))
+        assert info[b].n_features == oinfo.n_fast and info[b].n_matched == oinfo.n_matched and info[b].n_object_points == oinfo.n_obj
+        assert bool(info[b].ok) == bool(oinfo.pnp.ok), b
+        if oinfo.pnp.ok:
+            assert np.abs(Rt[b] - want).max() <= 1e-3
+        assert np.array_equal(ctx.disparity16(b), ob.sgbm(lt1[b], rt1[b], op))
+    assert info[1].n_features == 0 and not info[1].ok
+    # the ordinary pairs give what they give alone
+    one = abi.Context(abi.default_params(W, H, max_batch=1, num_disparities=64, max_features=4096))
+    one.set_calib(seq.P0, seq.P1)
+    one.set_images(lt1[2], rt1[2], lt2[2], rt2[2])
+    Rt1, _ = one.step()
+    assert np.array_equal(Rt1[0], Rt[2])
+    one.close(); ctx.close()

@@ -265,21 +265,29 @@ class Context:
         self._check(self._L.vo_estimate_motion(self._h, _ptr(Rt), info))
         return Rt, list(info)
 
-    def step(self):
+    def _check_step(self, rc, strict):
+        # VO_ERR_NOT_ENOUGH_POINTS leaves every frame's outputs filled (the failed frames have ok = 0, identity [R|t])
+        if rc == -7 and not strict:
+            return
+        self._check(rc)
+
+    def step(self, strict=True):
+        """One main-loop iteration for the n frame pairs that are set.  strict=False: frames with too few correspondences
+        are reported through info[b].ok == 0 instead of raising, the other frames of the batch keep their results."""
         n = self.n
         Rt = np.zeros((n, 4, 4), dtype=np.float64)
         info = (FrameInfo * n)()
-        self._check(self._L.vo_step(self._h, _ptr(Rt), info))
+        self._check_step(self._L.vo_step(self._h, _ptr(Rt), info), strict)
         return Rt, list(info)
 
     def step_submit(self):
         self._check(self._L.vo_step_submit(self._h))
 
-    def step_finish(self):
+    def step_finish(self, strict=True):
         n = self.n
         Rt = np.zeros((n, 4, 4), dtype=np.float64)
         info = (FrameInfo * n)()
-        self._check(self._L.vo_step_finish(self._h, _ptr(Rt), info))
+        self._check_step(self._L.vo_step_finish(self._h, _ptr(Rt), info), strict)
         return Rt, list(info)
 
     # --- per-stage timing
