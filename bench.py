@@ -227,6 +227,11 @@ def main():
     if world > 1:
         gathered = [torch.empty_like(poses) for _ in range(world)]
         dist.all_gather(gathered, poses)
+        # ... and the point clouds (triangulated points) of the last batch, as fixed-size padded buffers
+        from visualodometry_amd import sequence as vseq
+        last = ctxs[(args.steps - 1) % nctx]
+        clouds = vseq.gather_point_clouds([last.object_points(b)[0] for b in range(B)], cap=shape["max_features"])
+        assert len(clouds) == world
         torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
@@ -291,7 +296,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s-shape synthetic stereo, %dx%d, %d disparities, %d frame pairs per step per GPU, whole hot path "
                                    "(SGBM-3way + FAST + circular KLT + triangulation + PnP-RANSAC)" % (args.workload, W, H, D, B),
-                       "batch": B, "batches_in_flight": nctx, "input_mode": args.mode, "sharding": "independent sequences, one per GPU; poses all-gathered once (RCCL)",
+                       "batch": B, "batches_in_flight": nctx, "input_mode": args.mode, "sharding": "independent sequences, one per GPU; poses and the last batch's point clouds all-gathered once (RCCL)",
                        "mpix_per_s": fps * W * H / 1e6, "latency_ms_one_pair_alone": latency_ms,
                        "features_per_frame": int(np.mean([i.n_features for i in info])),
                        "matches_per_frame": int(np.mean([i.n_matched for i in info])),

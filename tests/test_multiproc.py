@@ -56,6 +56,22 @@ def chunk_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def cloud_of(rank, i):
+    rng = np.random.RandomState(10 * rank + i)
+    return rng.normal(0, 5, size=(3 + 2 * i + rank, 3)).astype(np.float32)
+
+
+def cloud_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    got = sequence.gather_point_clouds([cloud_of(rank, i) for i in range(3)], cap=16)
+    ok = all(np.array_equal(got[r][i], cloud_of(r, i)) for r in range(world) for i in range(3))
+    q.put((rank, ok, len(got)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -131,3 +147,23 @@ def test_chunk_sharding_and_gather_world2():
     want = {i: sequence.integrate(fake_sequence_Rts(i, LENGTHS[i] - 1).reshape(-1, 4, 4))[0][-1].tolist() for i in range(len(LENGTHS))}
     for rank, _, finals in res:
         assert finals == want, rank
+
+
+def test_point_cloud_gather_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=cloud_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True, 2), (1, True, 2)]
+    single = sequence.gather_point_clouds([cloud_of(0, 0)], cap=8)
+    assert len(single) == 1 and np.array_equal(single[0][0], cloud_of(0, 0))
+    import pytest
+    with pytest.raises(ValueError):
+        sequence.gather_point_clouds([cloud_of(0, 2)], cap=4)

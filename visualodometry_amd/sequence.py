@@ -111,3 +111,30 @@ def gather_trajectories(local, n_sequences, max_steps, group=None):
         buf = torch.stack(bufs).sum(0).cpu()   # every step is owned by exactly one rank; the others hold zeros there
         cnt = torch.stack(cnts).sum(0).cpu()
     return {i: buf[i, :int(cnt[i])].numpy().copy() for i in range(n_sequences) if int(cnt[i]) > 0}
+
+
+def gather_point_clouds(clouds, cap, group=None):
+    """clouds: this rank's list of [k_i, 3] float32 point sets (the triangulated points of its frame pairs, k_i <= cap), the
+    same number of sets on every rank.  One all_gather of fixed-size padded buffers (plus one of the counts); returns, on
+    every rank, a list over ranks of lists of [k_i, 3] arrays."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    n = len(clouds)
+    buf = torch.zeros((n, cap, 3), dtype=torch.float32)
+    cnt = torch.zeros((n,), dtype=torch.int64)
+    for i, pts in enumerate(clouds):
+        a = np.asarray(pts, dtype=np.float32).reshape(-1, 3)
+        if a.shape[0] > cap:
+            raise ValueError("point set %d has %d points, capacity %d" % (i, a.shape[0], cap))
+        buf[i, :a.shape[0]] = torch.from_numpy(a)
+        cnt[i] = a.shape[0]
+    if world == 1:
+        return [[buf[i, :int(cnt[i])].numpy().copy() for i in range(n)]]
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    buf, cnt = buf.to(dev), cnt.to(dev)
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    cnts = [torch.empty_like(cnt) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    dist.all_gather(cnts, cnt, group=group)
+    return [[bufs[r][i, :int(cnts[r][i])].cpu().numpy().copy() for i in range(n)] for r in range(world)]
