@@ -285,6 +285,22 @@ def main():
             except Exception:
                 traffic = None
 
+        # vector-instruction side of the same kernels (the tracker is bound by issue, not by HBM): share of the chip's
+        # issue capacity = instructions x cycles per instruction / (SIMDs x clock x duration)
+        valu = None
+        vf = os.path.join(ROOT, "profiles", "valu.json")
+        if os.path.exists(vf):
+            try:
+                vj = json.load(open(vf)).get(args.workload, {})
+                valu = {}
+                for k, v in vj.items():
+                    if isinstance(v, dict) and excl.get(k, 0) > 0:
+                        cyc = v["valu_insts_per_launch"] * v["issue_cycles_per_inst"] / vj["simds"]
+                        valu[k] = {"valu_insts_per_launch": v["valu_insts_per_launch"], "issue_cycles_per_inst": v["issue_cycles_per_inst"],
+                                   "frac_of_issue_capacity": round(cyc / (vj["sclk_ghz"] * 1e9 * excl[k] * 1e-3), 3)}
+            except Exception:
+                valu = None
+
         def frac(ms, k):
             return round(kb[k] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms.get(k, 0) > 0 else None
 
@@ -309,6 +325,7 @@ def main():
                          "streaming_GBs_measured": {"read": 6290, "write": 3890, "copy": 4450, "1_read_4_writes": 4440},
                          "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": excl.get(dom, 0.0),
                          "avg_launch_ms_timed_region": stage_ms.get(dom, 0.0), "frac_timed_region": frac(stage_ms, dom),
+                         "valu_issue": valu,
                          "measured": "HIP events on the kernel's stream, one batch in flight, right after the timed region"
                                      if isolated else "HIP events on the kernel's stream over the timed region",
                          # the tracker and the resolve pass are bound by vector instruction issue, not by HBM: their
