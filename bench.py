@@ -116,13 +116,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=0, help="frame pairs per step (default: 16 at KITTI shape, 8 at 4K)")
     ap.add_argument("--workload", default="kitti", choices=["kitti", "4k"])
     ap.add_argument("--distinct", type=int, default=4, help="distinct frame pairs rendered (tiled to fill the batch)")
     ap.add_argument("--cpu-pairs", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0)
-    ap.add_argument("--inflight", type=int, default=3, help="contexts taking turns (overlaps host PnP with GPU work)")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="contexts taking turns (overlaps host PnP with GPU work; default: 3 at KITTI shape, 2 at 4K, "
+                         "where a context holds 5.5 GB per frame pair)")
     ap.add_argument("--latency", action="store_true",
                     help="also time one frame pair alone (batch of 1) after the run; off by default so that a kernel profile "
                          "of the default command holds launches of one batch size only")
@@ -130,6 +132,10 @@ def main():
                     help="pairs: B independent frame pairs, 4 pyramids each (what the reference rebuilds per step); "
                          "sequence: B + 1 consecutive frames, every frame pyramided once")
     args = ap.parse_args()
+    if args.batch <= 0:
+        args.batch = 8 if args.workload == "4k" else 16
+    if args.inflight <= 0:
+        args.inflight = 2 if args.workload == "4k" else 3
 
     import torch
     import torch.distributed as dist
