@@ -195,7 +195,7 @@ __device__ __forceinline__ void store_pk_buf(__amdgpu_buffer_rsrc_t rs, unsigned
 struct StripeInfo { int y0[4], rows[4], off[4], out0[4]; };
 
 // ---------------------------------------------------------------- pixel cost + 11x11 window + top-down path, fused
-// Block = VO_COST_THREADS threads in lane groups of 16; a lane group owns NCOL adjacent tile columns (CV_COLS per block,
+// Block = vo_cost_threads(NP) threads in lane groups of 16; a lane group owns NCOL adjacent tile columns (CV_COLS per block,
 // SW2 of them on each side are halo), a lane 2*NP consecutive disparities of each.  Marching down the stripe:
 //   V(x, d)  = running vertical window sum of the pixel cost.  The row that enters the window is evaluated from the
 //              prefiltered rows; the row that leaves it was evaluated block_size steps earlier by the same thread and
@@ -207,10 +207,11 @@ struct StripeInfo { int y0[4], rows[4], off[4], out0[4]; };
 // SWC: the half window as a compile-time constant (0 = use the run-time SW2; slower horizontal sum)
 // NCOL: tile columns per lane group (4; 2 for wide disparity ranges, where 4 columns x 2NP cells do not fit the registers)
 template <int NP, int SWC, int NCOL>
-__global__ __launch_bounds__(VO_COST_THREADS) void cost_vpath_kernel(const uint2* __restrict__ pre, int W, int H, int Wp, int width1, int D, int SW2,
+__global__ __launch_bounds__(vo_cost_threads(NP)) void cost_vpath_kernel(const uint2* __restrict__ pre, int W, int H, int Wp, int width1, int D, int SW2,
                                                          int srows, StripeInfo si, int P1, int P2, int16_t* __restrict__ cost,
                                                          int16_t* __restrict__ agg, uint32_t* __restrict__ ring, int lds_slots)
 {
+    constexpr int VO_COST_THREADS = vo_cost_threads(NP);
     constexpr int CV_COLS = (VO_COST_THREADS / 16) * NCOL;
     extern __shared__ int vt[]; // [2][CV_COLS][CS]: V of every tile column, dword (k, lane16) at k*16 + lane16
     constexpr int CS = 16 * NP + 4;
@@ -677,16 +678,19 @@ int run_sgbm(vo_ctx* c)
     // the reference's window (11x11, Source/VOClass.cpp:242) gets the instantiation with a compile-time half window
     const int swc = SH2 == 5 ? 5 : 0;
     constexpr int NCOL = vo_cost_group_cols(NP);
+    constexpr int VO_COST_THREADS = vo_cost_threads(NP);
     constexpr int TILE_COLS = (VO_COST_THREADS / 16) * NCOL;
     // LDS: the double-buffered tile, plus as many ring slots as fit a third of a CU's 160 KB (three blocks per CU
-    // is what the kernel's register use allows at 96 disparities)
+    // is what the kernel's register use allows at 96 disparities); the 512-thread blocks of the wide disparity ranges
+    // are alone on their CU (two wavefronts per SIMD at ~200 registers) and take nearly all of it
 #ifndef VO_COST_LDS_BUDGET
 #define VO_COST_LDS_BUDGET (52 * 1024)
 #endif
+    const size_t lds_budget = VO_COST_THREADS > 256 ? (size_t)150 * 1024 : (size_t)VO_COST_LDS_BUDGET;
     const size_t tile_bytes = (size_t)2 * TILE_COLS * (16 * NP + 4) * sizeof(int);
     const size_t slot_bytes = (size_t)(NCOL * NP / 2) * VO_COST_THREADS * sizeof(unsigned);
-    const int lds_slots = tile_bytes >= (size_t)VO_COST_LDS_BUDGET ? 0
-                        : (int)std::min<size_t>((VO_COST_LDS_BUDGET - tile_bytes) / slot_bytes, (size_t)(2 * SH2 + 2));
+    const int lds_slots = tile_bytes >= lds_budget ? 0
+                        : (int)std::min<size_t>((lds_budget - tile_bytes) / slot_bytes, (size_t)(2 * SH2 + 2));
     const size_t lds = tile_bytes + lds_slots * slot_bytes;
     const void* fn = swc ? reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 5, NCOL>) : reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 0, NCOL>);
     static bool lds_attr_set[64][2]; // per device: a kernel's attributes belong to the device's copy of the code object

@@ -130,15 +130,17 @@ int vo_fail(vo_ctx* c, int code, const char* fmt, ...);
         if (e__ != hipSuccess) return vo_fail((c), VO_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
     } while (0)
 
-// cost kernel tiling: a block of VO_COST_THREADS threads in lane groups of 16; a group owns vo_cost_group_cols() adjacent
-// cost columns (4; 2 once a lane holds 12 or more disparities of each), block_size / 2 columns on each side of the tile are halo
-#ifndef VO_COST_THREADS
-#define VO_COST_THREADS 256
+// cost kernel tiling: a block of vo_cost_threads() threads in lane groups of 16; a group owns vo_cost_group_cols() adjacent
+// cost columns (4; 2 once a lane holds 12 or more disparities of each, and then twice the threads, so that a tile stays
+// 64 columns wide); block_size / 2 columns on each side of the tile are halo
+#ifndef VO_COST_WIDE_THREADS
+#define VO_COST_WIDE_THREADS 512
 #endif
 constexpr int vo_cost_group_cols(int pairs_per_lane) { return pairs_per_lane >= 6 ? 2 : 4; }
+constexpr int vo_cost_threads(int pairs_per_lane) { return pairs_per_lane >= 6 ? VO_COST_WIDE_THREADS : 256; }
 inline size_t vo_cost_tiles(const vo_ctx* c)
 {
-    const int tile_out = (VO_COST_THREADS / 16) * vo_cost_group_cols(c->D / 32) - 2 * (c->p.block_size / 2);
+    const int tile_out = (vo_cost_threads(c->D / 32) / 16) * vo_cost_group_cols(c->D / 32) - 2 * (c->p.block_size / 2);
     return (size_t)((c->width1 + tile_out - 1) / tile_out);
 }
 // dwords of the pixel-cost ring per thread and slot (4 byte costs per dword)
