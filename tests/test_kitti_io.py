@@ -109,3 +109,9 @@ def test_depth_ply_matches_the_reference_writer(tmp_path):
     assert written == header == 4
     # float(2999.9999) == 3000.0f, which is not > 3000: kept, printed with 6 significant digits
     assert lines[10:] == ["0 0 -10.5 1 1 1", "1 0 -3000 3 3 3", "2 0 -3000 5 5 5", "2 1 -7.25 6 6 6"]
+
+
+def test_command_line_parses_and_fails_cleanly_without_frames(tmp_path):
+    """python -m visualodometry_amd.kitti DIR: an empty directory is an error before anything touches a GPU"""
+    with pytest.raises((ValueError, FileNotFoundError, OSError)):
+        kitti.main([str(tmp_path), "--out", str(tmp_path / "o.txt")])

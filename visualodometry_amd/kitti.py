@@ -282,3 +282,27 @@ def write_depth_ply(path, depth, gray, depth_thresh=3000):
         gg = gray[rows, cols]
         f.write("".join("%d %d %g %d %d %d\n" % (r, c, v, g, g, g) for r, c, v, g in zip(rows.tolist(), cols.tolist(), zz.tolist(), gg.tolist())))
     return len(rows), n_vertices
+
+
+def main(argv=None):
+    """python -m visualodometry_amd.kitti SEQUENCE_DIR [--poses FILE] [--out FILE] [--batch B] [--limit N] [--device D]
+    The reference's main() on a KITTI odometry sequence directory (image_0/, image_1/, calib.txt): writes the "x y z"
+    pose dump the reference writes to Log/outputPoses.txt and prints the translation RMSE when ground truth is given."""
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m visualodometry_amd.kitti", description=main.__doc__)
+    ap.add_argument("sequence_dir")
+    ap.add_argument("--poses", default=None, help="ground-truth poses file (12 numbers per line)")
+    ap.add_argument("--out", default="outputPoses.txt")
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--limit", type=int, default=None, help="use only the first N frames")
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    traj, err = run(a.sequence_dir, poses_file=a.poses, out_file=a.out, batch=a.batch, limit=a.limit, device=a.device)
+    print("%d poses written to %s" % (len(traj), a.out))
+    if err is not None:
+        print("Measured error: %g" % err)   # as the reference prints it (Source/main.cpp:63-65)
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
