@@ -602,17 +602,16 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
     const double K[9] = {c->P0[0], c->P0[1], c->P0[2], c->P0[4], c->P0[5], c->P0[6], c->P0[8], c->P0[9], c->P0[10]};
     const float thresh2 = (float)((double)c->p.ransac_reproj * (double)c->p.ransac_reproj);
 
-    // correspondences of every frame to the host (pinned staging)
-    size_t need = 0;
-    std::vector<size_t> off(n);
-    for (int b = 0; b < n; b++) { off[b] = need; need += (size_t)c->h_nobj[b] * (sizeof(vo_point3f) + sizeof(vo_point2f)); need = (need + 15) & ~(size_t)15; }
-    if (need > c->h_stage_bytes) return vo_fail(c, VO_ERR_CAPACITY, "staging buffer too small");
-    for (int b = 0; b < n; b++) {
-        const int k = c->h_nobj[b];
-        if (k == 0) continue;
-        char* dst = (char*)c->h_stage + off[b];
-        VO_HIP(c, hipMemcpyAsync(dst, c->obj + b * F, (size_t)k * sizeof(vo_point3f), hipMemcpyDeviceToHost, c->stream));
-        VO_HIP(c, hipMemcpyAsync(dst + (size_t)k * sizeof(vo_point3f), c->obj_img + b * F, (size_t)k * sizeof(vo_point2f), hipMemcpyDeviceToHost, c->stream));
+    // correspondences of every frame to the host (pinned staging): two strided copies, [n][kmax] points each
+    int kmax = 0;
+    for (int b = 0; b < n; b++) kmax = std::max(kmax, c->h_nobj[b]);
+    const size_t obj_bytes = (size_t)n * kmax * sizeof(vo_point3f), img_off = (obj_bytes + 15) & ~(size_t)15;
+    if (img_off + (size_t)n * kmax * sizeof(vo_point2f) > c->h_stage_bytes) return vo_fail(c, VO_ERR_CAPACITY, "staging buffer too small");
+    if (kmax > 0) {
+        VO_HIP(c, hipMemcpy2DAsync(c->h_stage, (size_t)kmax * sizeof(vo_point3f), c->obj, F * sizeof(vo_point3f), (size_t)kmax * sizeof(vo_point3f), n,
+                                   hipMemcpyDeviceToHost, c->stream));
+        VO_HIP(c, hipMemcpy2DAsync((char*)c->h_stage + img_off, (size_t)kmax * sizeof(vo_point2f), c->obj_img, F * sizeof(vo_point2f),
+                                   (size_t)kmax * sizeof(vo_point2f), n, hipMemcpyDeviceToHost, c->stream));
     }
     VO_HIP(c, hipStreamSynchronize(c->stream));
     // own copies: the staging buffer is reused for hypotheses and masks below
@@ -622,9 +621,10 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
     int status = VO_OK;
     for (int b = 0; b < n; b++) {
         const int k = c->h_nobj[b];
-        const char* src = (const char*)c->h_stage + off[b];
-        objs[b].assign((const vo_point3f*)src, (const vo_point3f*)src + k);
-        imgs[b].assign((const vo_point2f*)(src + (size_t)k * sizeof(vo_point3f)), (const vo_point2f*)(src + (size_t)k * sizeof(vo_point3f)) + k);
+        const vo_point3f* so = (const vo_point3f*)c->h_stage + (size_t)b * kmax;
+        const vo_point2f* si = (const vo_point2f*)((const char*)c->h_stage + img_off) + (size_t)b * kmax;
+        objs[b].assign(so, so + k);
+        imgs[b].assign(si, si + k);
         FrameRansac& f = fr[b];
         f.k = k; f.obj = objs[b].data(); f.img = imgs[b].data();
         f.niters = std::max(c->p.ransac_iters, 1);
@@ -635,6 +635,11 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
 
     double* h_hyp = (double*)c->h_stage;                         // [n][chunk][12]
     int* h_cnt = (int*)((char*)c->h_stage + (size_t)n * chunk * 12 * sizeof(double)); // [n][chunk]
+    // inlier masks of a round's hypotheses, [n][chunk][kmax] bytes: fetched together with the counts (one strided copy, one
+    // wait per round) rather than per frame after the counts have been looked at
+    const size_t mask_off = ((size_t)n * chunk * (12 * sizeof(double) + sizeof(int)) + 255) & ~(size_t)255;
+    const bool masks_fit = mask_off + (size_t)n * chunk * kmax <= c->h_stage_bytes;
+    uint8_t* h_mask = (uint8_t*)c->h_stage + mask_off;
     for (;;) {
         bool any = false;
         for (int b = 0; b < n; b++) any = any || (fr[b].active && fr[b].iter < fr[b].niters);
@@ -663,6 +668,8 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
         int rc = launch_pnp_score(c, 0, n, chunk, thresh2, true);
         if (rc) return rc;
         VO_HIP(c, hipMemcpyAsync(h_cnt, c->hyp_count, (size_t)n * chunk * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        if (masks_fit && kmax > 0)
+            VO_HIP(c, hipMemcpy2DAsync(h_mask, (size_t)kmax, c->hyp_mask, F, (size_t)kmax, (size_t)n * chunk, hipMemcpyDeviceToHost, c->stream));
         VO_HIP(c, hipStreamSynchronize(c->stream));
         // replay the sequential accept rule; hypotheses past the shrinking iteration budget are discarded
         for (int b = 0; b < n; b++) {
@@ -684,6 +691,7 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
             FrameRansac& f = fr[b];
             if (f.best_h < 0) continue;
             f.best_mask.resize(f.k);
+            if (masks_fit) { memcpy(f.best_mask.data(), h_mask + ((size_t)b * chunk + f.best_h) * kmax, (size_t)f.k); continue; }
             VO_HIP(c, hipMemcpyAsync(f.best_mask.data(), c->hyp_mask + ((size_t)b * chunk + f.best_h) * F, (size_t)f.k, hipMemcpyDeviceToHost, c->stream));
             fetch = true;
         }
