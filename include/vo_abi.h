@@ -207,7 +207,7 @@ int vo_pyramid_info(vo_ctx* ctx, int level, int* w, int* h, int* max_level);
  * calls: how many times each stage ran since the last reset.  No counterpart in the reference. */
 #define VO_NUM_STAGES 16
 typedef enum {
-    VO_ST_PREFILTER = 0, VO_ST_HSUM = 1, VO_ST_VPATH = 2, VO_ST_HPATH_FWD = 3, VO_ST_HPATH_BWD = 4, VO_ST_LRCHECK = 5,
+    VO_ST_PREFILTER = 0, /* 1: not in use */ VO_ST_VPATH = 2, VO_ST_HPATH_FWD = 3, VO_ST_HPATH_BWD = 4, VO_ST_LRCHECK = 5,
     VO_ST_MEDIAN = 6, VO_ST_FAST = 7, VO_ST_PYRAMID = 8, VO_ST_LK = 9, VO_ST_FILTER = 10, VO_ST_TRIANGULATE = 11,
     VO_ST_PNP_SCORE = 12, VO_ST_PNP_HOST = 13, VO_ST_STEP_WALL = 14
 } vo_stage;

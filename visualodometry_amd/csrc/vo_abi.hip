@@ -601,7 +601,7 @@ extern "C" int vo_step(vo_ctx* c, double* Rt_out, vo_frame_info* info)
     return vo_step_finish(c, Rt_out, info);
 }
 
-static const char* kStageNames[VO_NUM_STAGES] = {"sgbm_prefilter", "unused", "sgbm_cost_vpath", "sgbm_hpath_ckpt", "sgbm_hpath_resolve",
+static const char* kStageNames[VO_NUM_STAGES] = {"sgbm_prefilter", "", "sgbm_cost_vpath", "sgbm_hpath_ckpt", "sgbm_hpath_resolve",
     "sgbm_lrcheck", "sgbm_median", "fast", "pyramid", "lk", "klt_filter", "triangulate", "pnp_score", "pnp_host", "step_wall", ""};
 
 extern "C" const char* vo_stage_name(int s) { return s >= 0 && s < VO_NUM_STAGES ? kStageNames[s] : ""; }
