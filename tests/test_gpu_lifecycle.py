@@ -1,0 +1,80 @@
+"""Context life cycle and threading contract through the C ABI: contexts are independent (own stream, own buffers), one
+context is used by one thread at a time, and destroying a context gives its memory back."""
+import threading
+
+import numpy as np
+import pytest
+
+from visualodometry_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+W, H = 320, 96
+PARAMS = dict(num_disparities=64, max_features=4096)
+
+
+@pytest.fixture(scope="module")
+def pairs():
+    seq = synth.Sequence(seed=99, width=W, height=H)
+    f = [seq.frame(i) for i in range(4)]
+    return seq, f
+
+
+def run_one(seq, f, i, batch=1):
+    ctx = abi.Context(abi.default_params(W, H, max_batch=batch, **PARAMS))
+    ctx.set_calib(seq.P0, seq.P1)
+    ctx.set_images(f[i][0], f[i][1], f[i + 1][0], f[i + 1][1])
+    Rt, info = ctx.step()
+    d = ctx.disparity16(0).copy()
+    ctx.close()
+    return Rt[0], d, info[0].n_matched
+
+
+def test_create_destroy_returns_device_memory(pairs):
+    import torch
+    seq, f = pairs
+    run_one(seq, f, 0)          # first use loads the code object and creates the shared stream
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(12):
+        run_one(seq, f, 0, batch=4)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert abs(free0 - free1) < 64 << 20, (free0, free1)   # nothing accumulates (a context of this size holds ~0.5 GB)
+
+
+def test_contexts_on_concurrent_threads_are_independent(pairs):
+    seq, f = pairs
+    want = [run_one(seq, f, i) for i in range(3)]
+    got = [None] * 3
+    errs = []
+
+    def work(i):
+        try:
+            ctx = abi.Context(abi.default_params(W, H, max_batch=1, **PARAMS))
+            ctx.set_calib(seq.P0, seq.P1)
+            for _ in range(5):   # repeated steps interleave with the other threads' steps
+                ctx.set_images(f[i][0], f[i][1], f[i + 1][0], f[i + 1][1])
+                Rt, info = ctx.step()
+            got[i] = (Rt[0], ctx.disparity16(0).copy(), info[0].n_matched)
+            ctx.close()
+        except Exception as e:   # surfaced below
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(3):
+        assert np.array_equal(got[i][0], want[i][0]) and np.array_equal(got[i][1], want[i][1]) and got[i][2] == want[i][2]
+
+
+def test_use_after_close_is_an_error_not_a_crash(pairs):
+    seq, f = pairs
+    ctx = abi.Context(abi.default_params(W, H, max_batch=1, **PARAMS))
+    ctx.close()
+    ctx.close()   # idempotent
+    with pytest.raises((abi.VoError, ValueError, RuntimeError)):
+        ctx.step()
