@@ -136,6 +136,12 @@ int vo_get_disparity32(vo_ctx* ctx, int b, float* out /* H*W */);
  * (0 and -1 become 0.1f) and produces the f64 depth map. */
 int vo_compute_depth_map(vo_ctx* ctx);
 int vo_get_depth(vo_ctx* ctx, int b, double* out /* H*W */);
+/* The vertices VOClass::writeToPLY lists for the depth map of frame b (Source/VOClassUtils.cpp:132-148, called from
+ * Source/VOClass.cpp:330-360): every pixel whose depth, narrowed to float, is not above depth_thresh, in row-major
+ * order, as (row, col, -z, grey of imgLT1).  Compacted on the GPU; out nullable (count only), at most cap records are
+ * copied, *n_out is the full count. */
+typedef struct { int row, col; float neg_z; uint8_t gray, pad[3]; } vo_cloud_point;
+int vo_get_depth_cloud(vo_ctx* ctx, int b, vo_cloud_point* out, int cap, int* n_out);
 
 /* VOClass::getFeaturesFAST(imgLT1) (Source/VOClassFeatures.cpp:7-39). */
 int vo_detect_fast(vo_ctx* ctx);

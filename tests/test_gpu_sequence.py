@@ -96,6 +96,28 @@ def test_depth_point_cloud_export(frames5, tmp_path):
     assert header == W * H - int(np.count_nonzero(depth.astype(np.int64) == int(depth.max())))
     r, c, z = lines[10].split()[:3]
     assert float(z) == pytest.approx(-depth[int(r), int(c)], rel=1e-5)
+    # the same vertices compacted on the GPU: same records in the same order, and the same file body
+    cloud = ctx.depth_cloud(0)
+    z32 = depth.astype(np.float32)
+    rows, cols = np.nonzero(~(z32 > 3000))
+    assert len(cloud) == written
+    assert np.array_equal(cloud["row"], rows) and np.array_equal(cloud["col"], cols)
+    assert np.array_equal(cloud["neg_z"], -z32[rows, cols]) and np.array_equal(cloud["gray"], frames[0][0][rows, cols])
+    kitti.write_cloud_ply(str(tmp_path / "cloud.ply"), cloud, n_vertices=header)
+    assert (tmp_path / "cloud.ply").read_text() == (tmp_path / "depth.ply").read_text()
+    # a threshold that rejects pixels (everything farther than 20 m): count-only query, then a capped copy
+    near = abi.Context(abi.default_params(W, H, depth_thresh=20, **PARAMS))
+    near.set_calib(seq.P0, seq.P1)
+    near.set_images(frames[0][0], frames[0][1], frames[1][0], frames[1][1])
+    near.compute_disparity()
+    with pytest.raises(abi.VoError):
+        near.depth_cloud(0)            # no depth map yet
+    near.compute_depth_map()
+    c20 = near.depth_cloud(0)
+    keep = ~(near.depth(0).astype(np.float32) > 20)
+    assert 0 < len(c20) == int(keep.sum()) < W * H
+    assert np.array_equal(np.stack([c20["row"], c20["col"]], 1), np.argwhere(keep))
+    near.close()
     ctx.close()
 
 

@@ -21,13 +21,15 @@ EXPORTS = (
     "vo_default_params", "vo_create", "vo_destroy", "vo_last_error", "vo_create_error", "vo_stream", "vo_synchronize",
     "vo_set_calib", "vo_set_images", "vo_set_images_device", "vo_set_sequence", "vo_set_sequence_device",
     "vo_compute_disparity", "vo_get_disparity16",
-    "vo_get_disparity32", "vo_compute_depth_map", "vo_get_depth", "vo_detect_fast", "vo_get_features", "vo_set_features",
+    "vo_get_disparity32", "vo_compute_depth_map", "vo_get_depth", "vo_get_depth_cloud", "vo_detect_fast", "vo_get_features", "vo_set_features",
     "vo_match_klt", "vo_get_matches", "vo_get_klt_legs", "vo_set_matches", "vo_triangulate", "vo_get_object_points",
     "vo_pnp_score", "vo_estimate_motion", "vo_integrate_pose", "vo_step", "vo_step_submit", "vo_step_finish", "vo_read_tap", "vo_pyramid_info",
     "vo_set_timing", "vo_get_timing", "vo_stage_name",
     "vo_host_epnp", "vo_host_pnp_iterative", "vo_host_rng_subsets", "vo_host_rodrigues",
 )
 NUM_STAGES = 16
+# vo_cloud_point
+CLOUD_DTYPE = np.dtype([("row", np.int32), ("col", np.int32), ("neg_z", np.float32), ("gray", np.uint8), ("pad", np.uint8, (3,))])
 
 
 class Point2f(C.Structure):
@@ -196,6 +198,15 @@ class Context:
         out = np.empty((self.H, self.W), dtype=np.float64)
         self._check(self._L.vo_get_depth(self._h, b, _ptr(out)))
         return out
+
+    def depth_cloud(self, b=0):
+        """The vertices VOClass::writeToPLY lists for frame b's depth map, compacted on the GPU: a structured array with
+        fields row, col (int32), neg_z (float32), gray (uint8), in row-major order."""
+        n = C.c_int()
+        self._check(self._L.vo_get_depth_cloud(self._h, b, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), dtype=CLOUD_DTYPE)
+        self._check(self._L.vo_get_depth_cloud(self._h, b, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        return out[:n.value]
 
     # --- VOClass::getFeaturesFAST
     def detect_fast(self):

@@ -194,6 +194,8 @@ extern "C" void vo_destroy(vo_ctx* c)
                     c->row_count, c->row_off, c->n_feat, c->feat, c->pyr, c->der, c->legs, c->leg_status, c->m1, c->m2, c->n_match,
                     c->obj, c->obj_img, c->n_obj, c->hyp, c->hyp_count, c->hyp_mask};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (c->cloud) (void)hipFree(c->cloud);
+    if (c->cloud_rows) (void)hipFree(c->cloud_rows);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
     if (c->host_pool) pnp_host::destroy_pool(c->host_pool);
@@ -360,6 +362,21 @@ extern "C" int vo_get_depth(vo_ctx* c, int b, double* out)
     CHECK_CTX(c); CHECK_B(c, b);
     if (!c->have_depth) return vo_fail(c, VO_ERR_STATE, "depth map not computed");
     return d2h(c, out, c->depth + (size_t)b * c->W * c->H, (size_t)c->W * c->H * sizeof(double));
+}
+
+extern "C" int vo_get_depth_cloud(vo_ctx* c, int b, vo_cloud_point* out, int cap, int* n_out)
+{
+    CHECK_CTX(c); CHECK_B(c, b);
+    if (!n_out || cap < 0) return vo_fail(c, VO_ERR_BAD_ARG, "null count pointer or negative capacity");
+    if (!c->have_depth) return vo_fail(c, VO_ERR_STATE, "depth map not computed");
+    VO_HIP(c, hipSetDevice(c->device));
+    int count = 0;
+    const int rc = launch_depth_cloud(c, b, &count);
+    if (rc) return rc;
+    *n_out = count;
+    const int k = std::min(count, cap);
+    if (out && k > 0) return d2h(c, out, c->cloud, (size_t)k * sizeof(vo_cloud_point));
+    return VO_OK;
 }
 
 static int fetch_counts(vo_ctx* c, const int* dev, std::vector<int>& host)

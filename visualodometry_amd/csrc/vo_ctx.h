@@ -104,6 +104,7 @@ struct vo_ctx {
 
     // pinned host staging
     void* h_stage = nullptr; size_t h_stage_bytes = 0;
+    vo_cloud_point* cloud = nullptr; int* cloud_rows = nullptr; // dense point cloud of one frame, built on request
     int* h_counts = nullptr; // pinned: [3][max_batch] feature / match / object-point counts of the pending step
     void* host_pool = nullptr; // worker threads of the host-side solvers (pnp_host.cpp), created on first use
 
@@ -157,6 +158,7 @@ inline int vo_hpath_segments(const vo_ctx* c) { const int seg = vo_hpath_seg(c->
 int launch_fast(vo_ctx* c);
 int launch_sgbm(vo_ctx* c);
 int launch_depth_map(vo_ctx* c);
+int launch_depth_cloud(vo_ctx* c, int b, int* count);
 int launch_pyramids(vo_ctx* c);
 int launch_match_klt(vo_ctx* c, bool counts_on_host);
 int launch_triangulate(vo_ctx* c);

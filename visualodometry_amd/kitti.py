@@ -284,6 +284,19 @@ def write_depth_ply(path, depth, gray, depth_thresh=3000):
     return len(rows), n_vertices
 
 
+def write_cloud_ply(path, cloud, n_vertices=None):
+    """The same file from a cloud compacted on the GPU (Context.depth_cloud): one "row col -z g g g" line per record.
+    n_vertices: the header's count (the reference computes it with its own formula, see write_depth_ply); default: the
+    number of records."""
+    n_vertices = len(cloud) if n_vertices is None else n_vertices
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                "property uchar red\nproperty uchar green\nproperty uchar blue\nend_header\n" % n_vertices)
+        f.write("".join("%d %d %g %d %d %d\n" % (r, c, v, g, g, g)
+                        for r, c, v, g in zip(cloud["row"].tolist(), cloud["col"].tolist(), cloud["neg_z"].tolist(), cloud["gray"].tolist())))
+    return len(cloud)
+
+
 def main(argv=None):
     """python -m visualodometry_amd.kitti SEQUENCE_DIR [--poses FILE] [--out FILE] [--batch B] [--limit N] [--device D]
     The reference's main() on a KITTI odometry sequence directory (image_0/, image_1/, calib.txt): writes the "x y z"
