@@ -12,7 +12,7 @@
 
 int main(int argc, char** argv)
 {
-    if (argc < 3) { std::fprintf(stderr, "usage: %s frames.raw calib.txt\n", argv[0]); return 2; }
+    if (argc < 3) { std::fprintf(stderr, "usage: %s frames.raw calib.txt [num_disparities [first_frame.ply]]\n", argv[0]); return 2; }
     std::ifstream in(argv[1], std::ios::binary);
     int W = 0, H = 0, N = 0;
     in >> W >> H >> N;
@@ -42,6 +42,7 @@ int main(int argc, char** argv)
             read_frame(VO.imgLT2, VO.imgRT2);
             vo::Image<float> disparityMapT1 = VO.computeDisparity(VO.imgLT1, VO.imgRT1);
             vo::Image<double> depthMapT1 = VO.computeDepthMap(disparityMapT1);
+            if (i == 0 && argc > 4) VO.writeToPLY(argv[4]); /* the reference writes the cloud of a frame from here when asked to */
             std::vector<vo_point2f> featurePointsT1 = VO.getFeaturesFAST(VO.imgLT1);
             std::vector<vo_point2f> featurePointsT2 = VO.matchFeatureKLT(featurePointsT1);
             auto t = VO.estimateMotion(featurePointsT1, featurePointsT2, depthMapT1);

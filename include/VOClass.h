@@ -26,6 +26,7 @@
 #include <cmath>
 #include <memory>
 #include <stdexcept>
+#include <fstream>
 #include <string>
 #include <vector>
 
@@ -124,6 +125,27 @@ public:
         check(vo_get_depth(ctx, 0, depth.ptr()));
         for (float& d : *disparityMap.data) if (d == 0.0 || d == -1.0) d = 0.1;
         return depth;
+    }
+
+    /* point cloud of the current depth map as the reference writes it (VOClass::writeToPLY, Source/VOClassUtils.cpp:111-157,
+     * called from computeDepthMap, Source/VOClass.cpp:330-360): "row col -z g g g" for every pixel whose depth is not
+     * above depthThresh.  The vertices are compacted on the GPU; numVertices is the header's count as the caller computed
+     * it (the reference derives it from a histogram), by default the number of vertices written.  Call after computeDepthMap. */
+    int writeToPLY(const std::string& plyFilePath, int numVertices = -1)
+    {
+        int n = 0;
+        check(vo_get_depth_cloud(ctx, 0, nullptr, 0, &n));
+        std::vector<vo_cloud_point> pts((size_t)n);
+        if (n) check(vo_get_depth_cloud(ctx, 0, pts.data(), n, &n));
+        std::ofstream plyFile(plyFilePath);
+        if (!plyFile.is_open()) throw vo::Error(VO_ERR_BAD_ARG, "Unable to open .ply file");
+        plyFile << "ply" << std::endl << "format ascii 1.0" << std::endl << "element vertex " << (numVertices < 0 ? n : numVertices) << std::endl;
+        plyFile << "property float x" << std::endl << "property float y" << std::endl << "property float z" << std::endl;
+        plyFile << "property uchar red" << std::endl << "property uchar green" << std::endl << "property uchar blue" << std::endl;
+        plyFile << "end_header" << std::endl;
+        for (const vo_cloud_point& v : pts)
+            plyFile << v.row << " " << v.col << " " << v.neg_z << " " << (int)v.gray << " " << (int)v.gray << " " << (int)v.gray << "\n";
+        return n;
     }
 
     /* feature detection  (Source/VOClassFeatures.cpp:7-39) */

@@ -359,8 +359,18 @@ def test_cpp_voclass_main_loop(small_seq, tmp_path):
             f.write(l.tobytes()); f.write(r.tobytes())
     cal = tmp_path / "calib.txt"
     cal.write_text(" ".join(repr(float(v)) for v in list(seq.P0.reshape(-1)) + list(seq.P1.reshape(-1))))
-    out = subprocess.run([exe, str(raw), str(cal), "64"], capture_output=True, text=True, timeout=120)
+    ply = tmp_path / "first.ply"
+    out = subprocess.run([exe, str(raw), str(cal), "64", str(ply)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
+    # the point cloud of the first frame as VOClass::writeToPLY lists it: same vertices as the oracle's depth map gives
+    d32 = ob.disp_to_float(ob.sgbm(frames[0][0], frames[0][1], ob.default_params(SMALL_W, SMALL_H, num_disparities=64)))
+    depth = ob.depth_map(d32, seq.P0[0, 0], seq.P1[0, 3] / (-1 * seq.P0[0, 0]))
+    z32 = depth.astype(np.float32)
+    rows, cols = np.nonzero(~(z32 > 3000))
+    lines = ply.read_text().splitlines()
+    assert lines[2] == "element vertex %d" % len(rows) and len(lines) == 10 + len(rows)
+    want_lines = ["%d %d %g %d %d %d" % (r, c, -z32[r, c], g, g, g) for r, c, g in zip(rows.tolist(), cols.tolist(), frames[0][0][rows, cols].tolist())]
+    assert lines[10:] == want_lines
     got = np.array([[float(v) for v in line.split()] for line in out.stdout.strip().splitlines()])
     op = ob.default_params(SMALL_W, SMALL_H, num_disparities=64)
     pose = np.eye(4)
