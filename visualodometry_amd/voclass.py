@@ -60,6 +60,12 @@ class VOClass:
         disparityMap[(disparityMap == 0.0) | (disparityMap == -1.0)] = np.float32(0.1)
         return self.ctx.depth(0)
 
+    def writeToPLY(self, plyFilePath, numVertices=None):
+        """VOClass::writeToPLY (Source/VOClassUtils.cpp:111-157) for the current depth map: the vertices are compacted on
+        the GPU in the writer's order; numVertices is the header's count (default: the vertices written)."""
+        from . import kitti
+        return kitti.write_cloud_ply(plyFilePath, self.ctx.depth_cloud(0), numVertices)
+
     def getFeaturesFAST(self, img):
         self._sync_images(img, None)
         self.ctx.detect_fast()
