@@ -78,3 +78,26 @@ def test_use_after_close_is_an_error_not_a_crash(pairs):
     ctx.close()   # idempotent
     with pytest.raises((abi.VoError, ValueError, RuntimeError)):
         ctx.step()
+
+
+def test_padded_host_rows_give_the_same_results_as_packed_ones(pairs):
+    """vo_set_images with a row stride larger than the width (re-pitched 2D upload) against tightly packed frames (one
+    linear upload per image set)"""
+    import ctypes as C
+    seq, f = pairs
+    imgs = [f[0][0], f[0][1], f[1][0], f[1][1]]
+    ctx = abi.Context(abi.default_params(W, H, max_batch=1, **PARAMS))
+    ctx.set_calib(seq.P0, seq.P1)
+    ctx.set_images(*imgs)
+    Rt_a, _ = ctx.step()
+    d_a, k_a = ctx.disparity16(0).copy(), ctx.features(0).copy()
+    pad = 7
+    padded = [np.full((H, W + pad), 255, dtype=np.uint8) for _ in range(4)]
+    for p, im in zip(padded, imgs):
+        p[:, :W] = im
+    ptr = [p.ctypes.data_as(C.c_void_p) for p in padded]
+    rc = abi.lib().vo_set_images(ctx._h, 1, *ptr, C.c_size_t(W + pad), C.c_size_t((W + pad) * H))
+    assert rc == 0
+    Rt_b, _ = ctx.step()
+    assert np.array_equal(Rt_a, Rt_b) and np.array_equal(ctx.disparity16(0), d_a) and np.array_equal(ctx.features(0), k_a)
+    ctx.close()

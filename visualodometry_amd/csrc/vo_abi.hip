@@ -243,6 +243,25 @@ static int check_images(vo_ctx* c, int n, const void* a, const void* b, const vo
     return VO_OK;
 }
 
+// Host frames to the context's own image memory.  Tightly packed frames (stride == width, frames back to back) go up with
+// one linear copy per image set and keep their layout on the device; anything else is re-pitched by a 2D copy per frame
+// (slow from pageable memory: the runtime stages it row by row).
+static int upload_frames(vo_ctx* c, uint8_t* dst, const uint8_t* src, int frames, size_t stride, size_t frame_stride, bool packed)
+{
+    if (packed) {
+        VO_HIP(c, hipMemcpyAsync(dst, src, (size_t)frames * c->W * c->H, hipMemcpyHostToDevice, c->stream));
+        return VO_OK;
+    }
+    for (int f = 0; f < frames; f++)
+        VO_HIP(c, hipMemcpy2DAsync(dst + (size_t)f * c->own_fstride, c->own_pitch, src + (size_t)f * frame_stride, stride, c->W, c->H,
+                                   hipMemcpyHostToDevice, c->stream));
+    return VO_OK;
+}
+static bool frames_packed(const vo_ctx* c, int frames, size_t stride, size_t frame_stride)
+{
+    return stride == (size_t)c->W && (frames == 1 || frame_stride == (size_t)c->W * c->H);
+}
+
 extern "C" int vo_set_images(vo_ctx* c, int n, const uint8_t* lt1, const uint8_t* rt1, const uint8_t* lt2, const uint8_t* rt2,
                              size_t stride, size_t frame_stride)
 {
@@ -252,16 +271,17 @@ extern "C" int vo_set_images(vo_ctx* c, int n, const uint8_t* lt1, const uint8_t
     VO_HIP(c, hipSetDevice(c->device));
     const uint8_t* src[4] = {lt1, rt1, lt2, rt2};
     const size_t B = c->p.max_batch;
+    const bool packed = frames_packed(c, n, stride, frame_stride);
     for (int i = 0; i < 4; i++) {
         uint8_t* dst = c->img_own + (size_t)i * B * c->own_fstride;
-        for (int b = 0; b < n; b++)
-            VO_HIP(c, hipMemcpy2DAsync(dst + (size_t)b * c->own_fstride, c->own_pitch, src[i] + (size_t)b * frame_stride, stride, c->W, c->H,
-                                       hipMemcpyHostToDevice, c->stream));
+        rc = upload_frames(c, dst, src[i], n, stride, frame_stride, packed);
+        if (rc) return rc;
         c->img[i] = dst;
     }
     // the copies read pageable host memory: finish them before the caller may reuse its buffers
     VO_HIP(c, hipStreamSynchronize(c->stream));
-    c->pitch = c->own_pitch; c->fstride = c->own_fstride; c->n = n; c->seq_mode = false;
+    c->pitch = packed ? (size_t)c->W : c->own_pitch; c->fstride = packed ? (size_t)c->W * c->H : c->own_fstride;
+    c->n = n; c->seq_mode = false;
     invalidate(c);
     return VO_OK;
 }
@@ -287,15 +307,16 @@ extern "C" int vo_set_sequence(vo_ctx* c, int n_pairs, const uint8_t* left, cons
     VO_HIP(c, hipSetDevice(c->device));
     const uint8_t* src[2] = {left, right};
     const size_t B = c->p.max_batch;
+    const bool packed = frames_packed(c, n_pairs + 1, stride, frame_stride);
+    const size_t dev_fstride = packed ? (size_t)c->W * c->H : c->own_fstride;
     for (int i = 0; i < 2; i++) {
         uint8_t* dst = c->img_own + (size_t)i * (B + 1) * c->own_fstride; // 2 (B + 1) frames fit the 4 B frames of the pair layout
-        for (int f = 0; f <= n_pairs; f++)
-            VO_HIP(c, hipMemcpy2DAsync(dst + (size_t)f * c->own_fstride, c->own_pitch, src[i] + (size_t)f * frame_stride, stride, c->W, c->H,
-                                       hipMemcpyHostToDevice, c->stream));
-        c->img[i] = dst; c->img[i + 2] = dst + c->own_fstride;
+        rc = upload_frames(c, dst, src[i], n_pairs + 1, stride, frame_stride, packed);
+        if (rc) return rc;
+        c->img[i] = dst; c->img[i + 2] = dst + dev_fstride;
     }
     VO_HIP(c, hipStreamSynchronize(c->stream));
-    c->pitch = c->own_pitch; c->fstride = c->own_fstride; c->n = n_pairs; c->seq_mode = true;
+    c->pitch = packed ? (size_t)c->W : c->own_pitch; c->fstride = dev_fstride; c->n = n_pairs; c->seq_mode = true;
     invalidate(c);
     return VO_OK;
 }
