@@ -1,3 +1,5 @@
+"""Host-side timing of one context on sequence input: upload (vo_set_sequence) and step, then the per-stage timers.
+    python tools/prof_seq.py      (needs a GPU)"""
 import time, numpy as np, sys
 sys.path.insert(0, '.')
 from visualodometry_amd import abi, synth
