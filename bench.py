@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=0,
                     help="contexts taking turns (overlaps host PnP with GPU work; default: 3 at KITTI shape, 2 at 4K, "
                          "where a context holds 5.5 GB per frame pair)")
+    ap.add_argument("--upload", action="store_true",
+                    help="re-upload the batch's images from host memory before every step (PCIe-inclusive rate; the headline "
+                         "value is measured without it, inputs resident in HBM)")
     ap.add_argument("--latency", action="store_true",
                     help="also time one frame pair alone (batch of 1) after the run; off by default so that a kernel profile "
                          "of the default command holds launches of one batch size only")
@@ -197,16 +200,31 @@ def main():
     ctx = ctxs[0]
     nctx = len(ctxs)
 
+    host_imgs = None
+    if args.upload:
+        if args.mode == "pairs":
+            host_imgs = [t.cpu().numpy() for t in (lt1, rt1, lt2, rt2)]
+        else:
+            host_imgs = [left.cpu().numpy(), right.cpu().numpy()]
+
+    def submit(c):
+        if host_imgs is not None:   # host -> device copy of the whole batch, then the step
+            if args.mode == "pairs":
+                c.set_images(*host_imgs)
+            else:
+                c.set_sequence(*host_imgs)
+        c.step_submit()
+
     def run_steps(k):
         """k whole batches through the path, pipeline fill and drain included"""
         out = None
         for s in range(min(nctx, k)):
-            ctxs[s].step_submit()
+            submit(ctxs[s])
         for s in range(k):
             c = ctxs[s % nctx]
             out = c.step_finish()
             if s + nctx < k:
-                c.step_submit()
+                submit(c)
         return out
 
     if args.warmup > 0:
@@ -318,7 +336,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s-shape synthetic stereo, %dx%d, %d disparities, %d frame pairs per step per GPU, whole hot path "
                                    "(SGBM-3way + FAST + circular KLT + triangulation + PnP-RANSAC)" % (args.workload, W, H, D, B),
-                       "batch": B, "batches_in_flight": nctx, "input_mode": args.mode, "sharding": "independent sequences, one per GPU; poses and the last batch's point clouds all-gathered once (RCCL)",
+                       "batch": B, "batches_in_flight": nctx, "input_mode": args.mode, "inputs": "uploaded from host memory every step" if args.upload else "resident in HBM", "sharding": "independent sequences, one per GPU; poses and the last batch's point clouds all-gathered once (RCCL)",
                        "mpix_per_s": fps * W * H / 1e6, "latency_ms_one_pair_alone": latency_ms,
                        "features_per_frame": int(np.mean([i.n_features for i in info])),
                        "matches_per_frame": int(np.mean([i.n_matched for i in info])),
