@@ -72,6 +72,7 @@ def test_png_round_trip_every_filter(tmp_path):
         path = str(tmp_path / ("f%d.png" % ft))
         kitti.write_png_gray(path, img, filter_type=ft)
         assert np.array_equal(kitti.read_png_gray(path), img), ft
+        assert np.array_equal(kitti.read_png_gray(path, use_pil=False), img), ft   # the built-in decoder
     try:
         from PIL import Image
     except Exception:
@@ -80,10 +81,12 @@ def test_png_round_trip_every_filter(tmp_path):
         assert np.array_equal(np.array(Image.open(str(tmp_path / ("f%d.png" % ft)))), img)
     Image.fromarray(img).save(str(tmp_path / "pil.png"))
     assert np.array_equal(kitti.read_png_gray(str(tmp_path / "pil.png")), img)
+    assert np.array_equal(kitti.read_png_gray(str(tmp_path / "pil.png"), use_pil=False), img)
     rgb = rng.randint(0, 256, size=(9, 11, 3)).astype(np.uint8)
     Image.fromarray(rgb).save(str(tmp_path / "rgb.png"))
     want = ((rgb[..., 0].astype(int) * 4899 + rgb[..., 1].astype(int) * 9617 + rgb[..., 2].astype(int) * 1868 + 8192) >> 14).astype(np.uint8)
     assert np.array_equal(kitti.read_png_gray(str(tmp_path / "rgb.png")), want)
+    assert np.array_equal(kitti.read_png_gray(str(tmp_path / "rgb.png"), use_pil=False), want)
 
 
 def test_sequence_directory_layout(tmp_path):

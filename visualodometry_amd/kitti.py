@@ -134,8 +134,29 @@ def _unfilter(raw, h, stride, bpp):
     return out
 
 
-def read_png_gray(path):
-    """8-bit grey image of a PNG file (H x W uint8)."""
+def _rgb_to_gray(px):
+    """cv::imread(..., IMREAD_GRAYSCALE) of a colour file: fixed-point BT.601 weights, 14 fractional bits"""
+    r, g, b = (px[:, :, i].astype(np.int32) for i in range(3))
+    return ((r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14).astype(np.uint8)
+
+
+def read_png_gray(path, use_pil=True):
+    """8-bit grey image of a PNG file (H x W uint8).  Decoded by Pillow when it is installed (a C decoder: ~7 ms for a
+    KITTI frame); the built-in decoder below gives the same pixels and needs nothing but zlib, but its Average and Paeth
+    rows are undone pixel by pixel in Python (~200 ms for such a frame)."""
+    if use_pil:
+        try:
+            from PIL import Image
+        except Exception:
+            Image = None
+        if Image is not None:
+            with Image.open(path) as im:
+                if im.format == "PNG" and im.mode in ("L", "RGB", "RGBA", "LA"):
+                    a = np.array(im)
+                    if a.dtype == np.uint8:
+                        if a.ndim == 2:
+                            return np.ascontiguousarray(a)
+                        return np.ascontiguousarray(a[:, :, 0]) if a.shape[2] == 2 else _rgb_to_gray(a)
     with open(path, "rb") as f:
         data = f.read()
     if data[:8] != _PNG_SIG:
@@ -160,8 +181,7 @@ def read_png_gray(path):
     px = _unfilter(zlib.decompress(b"".join(idat)), h, w * channels, channels).reshape(h, w, channels)
     if channels <= 2:
         return np.ascontiguousarray(px[:, :, 0])
-    r, g, b = (px[:, :, i].astype(np.int32) for i in range(3))
-    return ((r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14).astype(np.uint8)
+    return _rgb_to_gray(px)
 
 
 def write_png_gray(path, img, filter_type=0):
@@ -232,7 +252,7 @@ def write_sequence(root, frames, P0, P1, poses=None, poses_file=None):
         write_poses(poses_file or os.path.join(root, "poses.txt"), poses)
 
 
-def run(root, poses_file=None, out_file=None, batch=16, limit=None, device=0, **params):
+def run(root, poses_file=None, out_file=None, batch=16, limit=None, device=0, decode_threads=16, **params):
     """The reference's main() (Source/main.cpp:7-74) on a KITTI sequence directory: returns (trajectory [n,3], RMSE or None)."""
     from . import abi
     seq = Sequence(root, poses_file)
@@ -246,12 +266,22 @@ def run(root, poses_file=None, out_file=None, batch=16, limit=None, device=0, **
     try:
         ctx.set_calib(seq.P0, seq.P1)
         Rts = []
-        # chunks of `batch` pairs share their boundary frame; only one chunk of images is held at a time
-        for s in range(0, n - 1, batch):
-            e = min(s + batch, n - 1)
-            frames = [seq.frame(i) for i in range(s, e + 1)]
-            Rt, _ = sequence.run_sequence(ctx, frames, batch)
-            Rts.extend(Rt)
+        # chunks of `batch` pairs share their boundary frame.  Frames are decoded on worker threads (the PNG decoder
+        # releases the interpreter lock), one chunk ahead of the chunk the GPU is working on.
+        from concurrent.futures import ThreadPoolExecutor
+        chunks = [(s, min(s + batch, n - 1)) for s in range(0, n - 1, batch)]
+        with ThreadPoolExecutor(max_workers=max(1, min(decode_threads, os.cpu_count() or 1))) as pool:
+            def request(k, have_first):
+                s, e = chunks[k]
+                return [pool.submit(seq.frame, i) for i in range(s + (1 if have_first else 0), e + 1)]
+            pending = request(0, False)
+            last = None
+            for k in range(len(chunks)):
+                frames = ([last] if last is not None else []) + [f.result() for f in pending]
+                last = frames[-1]
+                pending = request(k + 1, True) if k + 1 < len(chunks) else []
+                Rt, _ = sequence.run_sequence(ctx, frames, batch)
+                Rts.extend(Rt)
         traj, _ = sequence.integrate(Rts)
     finally:
         ctx.close()
