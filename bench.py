@@ -114,8 +114,8 @@ def cpu_baseline(frames, seq, shape, sample_pairs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="frame pairs per step (default: 16 at KITTI shape, 8 at 4K)")
     ap.add_argument("--workload", default="kitti", choices=["kitti", "4k"])
     ap.add_argument("--distinct", type=int, default=4, help="distinct frame pairs rendered (tiled to fill the batch)")
