@@ -153,3 +153,16 @@ def test_cpp_voclass_example_is_built_and_links():
         __graft_entry__.build()
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_abi_header_is_plain_c():
+    """include/vo_abi.h is the boundary: it must compile as C99 on its own (no C++ or torch types in any signature)"""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                        os.path.join(root, "include", "vo_abi.h")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
