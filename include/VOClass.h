@@ -57,25 +57,20 @@ class VOClass {
     int frameW, frameH;
     vo_ctx* ctx = nullptr;
     std::array<double, 12> projectionCL{}, projectionCR{};
-    const void* uploaded[4] = {nullptr, nullptr, nullptr, nullptr};
-    const void* disparityOf[2] = {nullptr, nullptr};
     std::vector<std::array<double, 3>> groundTruth;
 
     void check(int rc) const { if (rc != VO_OK) throw vo::Error(rc, vo_last_error(ctx)); }
 
-    /* makes the device copies match the four member images (or the two images passed to computeDisparity) */
+    /* uploads the four member images (or the two images passed to computeDisparity / getFeaturesFAST).  Always: the
+     * reference re-reads its cv::Mat arguments and members on every call, so pixels rewritten in place must be seen */
     void syncImages(const vo::Image<uint8_t>* lt1 = nullptr, const vo::Image<uint8_t>* rt1 = nullptr)
     {
         const vo::Image<uint8_t>& a = lt1 ? *lt1 : imgLT1;
         const vo::Image<uint8_t>& b = rt1 ? *rt1 : imgRT1;
         const vo::Image<uint8_t>& c = imgLT2.empty() ? a : imgLT2;
         const vo::Image<uint8_t>& d = imgRT2.empty() ? b : imgRT2;
-        const void* key[4] = {a.ptr(), b.ptr(), c.ptr(), d.ptr()};
-        if (key[0] == uploaded[0] && key[1] == uploaded[1] && key[2] == uploaded[2] && key[3] == uploaded[3]) return;
         if (a.rows != frameH || a.cols != frameW) throw vo::Error(VO_ERR_BAD_ARG, "image size differs from frameW x frameH");
         check(vo_set_images(ctx, 1, a.ptr(), b.ptr(), c.ptr(), d.ptr(), (size_t)frameW, (size_t)frameW * frameH));
-        for (int i = 0; i < 4; i++) uploaded[i] = key[i];
-        disparityOf[0] = disparityOf[1] = nullptr;
     }
 
 public:
@@ -111,7 +106,6 @@ public:
     {
         syncImages(&leftImg, &rightImg);
         check(vo_compute_disparity(ctx));
-        disparityOf[0] = leftImg.ptr(); disparityOf[1] = rightImg.ptr();
         vo::Image<float> out(frameH, frameW);
         check(vo_get_disparity32(ctx, 0, out.ptr()));
         return out;
@@ -120,6 +114,8 @@ public:
     /* disparity to depth map  (Source/VOClass.cpp:312-366); patches disparityMap in place like the reference */
     vo::Image<double> computeDepthMap(vo::Image<float> disparityMap)
     {
+        if (disparityMap.rows != frameH || disparityMap.cols != frameW) throw vo::Error(VO_ERR_BAD_ARG, "disparity map size differs from frameW x frameH");
+        check(vo_set_disparity32(ctx, 0, disparityMap.ptr())); /* the map the caller hands over is the one converted */
         check(vo_compute_depth_map(ctx));
         vo::Image<double> depth(frameH, frameW);
         check(vo_get_depth(ctx, 0, depth.ptr()));
@@ -175,12 +171,13 @@ public:
         return t2;
     }
 
-    /* estimate motion  (Source/VOClass.cpp:370-623); the depth map argument is the one computeDepthMap returned
-     * for the current disparity (the device copy is used) */
+    /* estimate motion  (Source/VOClass.cpp:370-623); depths are looked up in the map the caller hands over */
     std::array<double, 3> estimateMotion(std::vector<vo_point2f> featurePointsT1, std::vector<vo_point2f> featurePointsT2,
-                                         vo::Image<double> /*depthMap*/)
+                                         vo::Image<double> depthMap)
     {
         if (featurePointsT1.size() != featurePointsT2.size()) throw vo::Error(VO_ERR_BAD_ARG, "matched arrays differ in size");
+        if (depthMap.rows != frameH || depthMap.cols != frameW) throw vo::Error(VO_ERR_BAD_ARG, "depth map size differs from frameW x frameH");
+        check(vo_set_depth(ctx, 0, depthMap.ptr()));
         check(vo_set_matches(ctx, 0, featurePointsT1.data(), featurePointsT2.data(), (int)featurePointsT1.size()));
         check(vo_triangulate(ctx));
         double Rt[16];

@@ -56,7 +56,7 @@ typedef struct {
     int max_features;         /* capacity per image; FAST output beyond it is truncated (row-major order) */
     /* StereoSGBM, MODE_SGBM_3WAY */
     int min_disparity;        /* 0 (only 0 is supported) */
-    int num_disparities;      /* 96; multiple of 16, <= 256 */
+    int num_disparities;      /* 96; multiple of 32 in [32, 256] (OpenCV itself takes any multiple of 16) */
     int block_size;           /* 11; odd, <= 13 (aggregated cost must fit 14 bits) */
     int p1, p2;               /* 968, 3872 */
     int disp12_max_diff;      /* 0 -> 1 */
@@ -136,6 +136,14 @@ int vo_get_disparity32(vo_ctx* ctx, int b, float* out /* H*W */);
  * (0 and -1 become 0.1f) and produces the f64 depth map. */
 int vo_compute_depth_map(vo_ctx* ctx);
 int vo_get_depth(vo_ctx* ctx, int b, double* out /* H*W */);
+/* Caller-supplied maps.  The reference's methods work on their ARGUMENTS: computeDepthMap(cv::Mat disparityMap)
+ * (Include/VOClass.h:85, Source/VOClass.cpp:312-366) converts whatever float map it is handed, and
+ * estimateMotion(..., cv::Mat depthMap) (Include/VOClass.h:98-100, Source/VOClass.cpp:418) looks depths up in whatever f64
+ * map it is handed.  vo_set_disparity32 replaces frame b's float disparity map (H*W floats, host memory) with the caller's,
+ * vo_set_depth frame b's depth map (H*W doubles); the stages downstream (vo_compute_depth_map, vo_triangulate) then read
+ * them.  In a batch of more than one frame the other frames must already hold computed maps. */
+int vo_set_disparity32(vo_ctx* ctx, int b, const float* disp /* H*W */);
+int vo_set_depth(vo_ctx* ctx, int b, const double* depth /* H*W */);
 /* The vertices VOClass::writeToPLY lists for the depth map of frame b (Source/VOClassUtils.cpp:132-148, called from
  * Source/VOClass.cpp:330-360): every pixel whose depth, narrowed to float, is not above depth_thresh, in row-major
  * order, as (row, col, -z, grey of imgLT1).  Compacted on the GPU; out nullable (count only), at most cap records are
@@ -201,7 +209,7 @@ typedef enum {
     VO_TAP_FAST_SCORE = 1,     /* u8 H*W */
     VO_TAP_DISP_PREMEDIAN = 2, /* s16 H*W */
     VO_TAP_COST_ROW = 3,       /* s16 width1*D: aggregated cost, arg0 = stripe, arg1 = image row */
-    VO_TAP_PYR_LEVEL = 4,      /* u8 h*w of pyramid level arg1 of image arg0 (0 LT1, 1 RT1, 2 RT2, 3 LT2) */
+    VO_TAP_PYR_LEVEL = 4,      /* u8 h*w of pyramid level arg1 of image arg0 (0 LT1, 1 RT1, 2 LT2, 3 RT2) */
     VO_TAP_DERIV_LEVEL = 5     /* s16 h*w*2 Scharr derivative of the same */
 } vo_tap;
 int vo_read_tap(vo_ctx* ctx, int tap, int b, int arg0, int arg1, void* out, size_t bytes);

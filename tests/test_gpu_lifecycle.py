@@ -101,3 +101,39 @@ def test_padded_host_rows_give_the_same_results_as_packed_ones(pairs):
     Rt_b, _ = ctx.step()
     assert np.array_equal(Rt_a, Rt_b) and np.array_equal(ctx.disparity16(0), d_a) and np.array_equal(ctx.features(0), k_a)
     ctx.close()
+
+
+def test_same_disparity_range_with_two_windows_in_one_process():
+    """The cost kernel's dynamic LDS grows with block_size (ring slots held in LDS): a small-window context created first
+    must not pin the kernel's LDS ceiling below what a larger window of the same disparity range needs."""
+    from oracle import binding as ob
+    w, h, D = 417, 57, 192
+    seq = synth.Sequence(seed=5151, width=w, height=h)
+    l, r = seq.frame(0)
+    for bs in (3, 7, 13, 5):
+        p = abi.default_params(w, h, max_batch=1, num_disparities=D, block_size=bs, max_features=1024)
+        ctx = abi.Context(p)
+        ctx.set_images(l, r, l, r)
+        ctx.compute_disparity()
+        op = ob.default_params(w, h, num_disparities=D, block_size=bs)
+        assert np.array_equal(ctx.disparity16(0), ob.sgbm(l, r, op)), bs
+        ctx.close()
+
+
+def test_setters_are_refused_between_submit_and_finish(pairs):
+    seq, f = pairs
+    ctx = abi.Context(abi.default_params(W, H, max_batch=1, **PARAMS))
+    ctx.set_calib(seq.P0, seq.P1)
+    ctx.set_images(f[0][0], f[0][1], f[1][0], f[1][1])
+    want, _ = ctx.step()
+    ctx.step_submit()
+    with pytest.raises(abi.VoError) as e:
+        ctx.set_images(f[1][0], f[1][1], f[2][0], f[2][1])
+    assert e.value.code == -5
+    with pytest.raises(abi.VoError):
+        ctx.set_features(np.zeros((4, 2), dtype=np.float32))
+    Rt, _ = ctx.step_finish()
+    assert np.array_equal(Rt, want)
+    ctx.set_images(f[1][0], f[1][1], f[2][0], f[2][1])   # accepted again
+    ctx.step()
+    ctx.close()

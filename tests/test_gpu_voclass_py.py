@@ -50,8 +50,69 @@ def test_main_loop_with_the_python_mirror(tmp_path):
     assert np.abs(np.array(estimatedTrajectory) - np.array(want)).max() <= 1e-3
 
 
-def test_depth_before_disparity_is_refused():
+def test_depth_without_images_is_refused():
     VO = VOClass(W, H, num_disparities=64, max_features=4096)
     with pytest.raises(Exception):
         VO.computeDepthMap(np.zeros((H, W), dtype=np.float32))
+    VO.close()
+
+
+def _loaded(seed=77):
+    seq = synth.Sequence(seed=seed, width=W, height=H)
+    frames = [seq.frame(i) for i in range(2)]
+    VO = VOClass(W, H, num_disparities=64, max_features=4096)
+    VO.setProjectionMatrices(seq.P0, seq.P1)
+    VO.imgLT1, VO.imgRT1 = frames[0]
+    VO.imgLT2, VO.imgRT2 = frames[1]
+    return seq, frames, VO
+
+
+def test_methods_work_on_their_map_arguments():
+    """computeDepthMap converts the map it is handed and estimateMotion looks depths up in the map it is handed
+    (Include/VOClass.h:85,98-100), not in whatever the device computed last."""
+    seq, frames, VO = _loaded()
+    disp = VO.computeDisparity(VO.imgLT1, VO.imgRT1)
+    # a caller-made disparity map: the computed one shifted by a quarter pixel where valid, plus a block of zeros
+    mine = disp.copy()
+    mine[mine > 0] += np.float32(0.25)
+    mine[10:20, 100:140] = 0.0
+    arg = mine.copy()
+    depth = VO.computeDepthMap(arg)
+    fx = seq.P0[0, 0]; base = seq.P1[0, 3] / (-fx)
+    want_disp = mine.copy()
+    want_depth = ob.depth_map(want_disp, fx, base)
+    assert np.array_equal(depth, want_depth) and np.array_equal(arg, want_disp)
+    f1 = VO.getFeaturesFAST(VO.imgLT1)
+    t1, t2 = VO.matchFeatureKLT(f1)
+    assert len(t1) > 50
+    # a caller-modified depth map: halve the depth of the left half, push a band beyond the depth threshold
+    dm = depth.copy()
+    dm[:, : W // 2] *= 0.5
+    dm[40:50, :] = 5000.0
+    VO.estimateMotion(t1, t2, dm)
+    obj_gpu, img_gpu = VO.ctx.object_points(0)
+    obj, _, i2 = ob.triangulate(t1, t2, dm, seq.P0)
+    assert len(obj) < len(t1)                      # the band was dropped
+    assert np.array_equal(obj_gpu, obj) and np.array_equal(img_gpu, i2)
+    # ... and with the unmodified map the object points differ
+    VO.poseRt = np.eye(4)
+    VO.estimateMotion(t1, t2, depth)
+    obj_gpu2, _ = VO.ctx.object_points(0)
+    assert obj_gpu2.shape != obj_gpu.shape or not np.array_equal(obj_gpu2, obj_gpu)
+    VO.close()
+
+
+def test_images_refilled_in_place_are_seen():
+    """The reference re-reads its cv::Mat members on every call: new pixels in the same buffers must be used."""
+    seq, frames, VO = _loaded(seed=78)
+    d0 = VO.computeDisparity(VO.imgLT1, VO.imgRT1)
+    f0 = VO.getFeaturesFAST(VO.imgLT1)
+    np.copyto(VO.imgLT1, frames[1][0])   # same arrays, new content
+    np.copyto(VO.imgRT1, frames[1][1])
+    d1 = VO.computeDisparity(VO.imgLT1, VO.imgRT1)
+    f1 = VO.getFeaturesFAST(VO.imgLT1)
+    op = ob.default_params(W, H, num_disparities=64)
+    assert np.array_equal(d1, ob.disp_to_float(ob.sgbm(frames[1][0], frames[1][1], op)))
+    assert np.array_equal(f1, ob.fast(frames[1][0]))
+    assert not np.array_equal(d0, d1) and not np.array_equal(f0, f1)
     VO.close()

@@ -21,7 +21,7 @@ EXPORTS = (
     "vo_default_params", "vo_create", "vo_destroy", "vo_last_error", "vo_create_error", "vo_stream", "vo_synchronize",
     "vo_set_calib", "vo_set_images", "vo_set_images_device", "vo_set_sequence", "vo_set_sequence_device",
     "vo_compute_disparity", "vo_get_disparity16",
-    "vo_get_disparity32", "vo_compute_depth_map", "vo_get_depth", "vo_get_depth_cloud", "vo_detect_fast", "vo_get_features", "vo_set_features",
+    "vo_get_disparity32", "vo_compute_depth_map", "vo_get_depth", "vo_set_disparity32", "vo_set_depth", "vo_get_depth_cloud", "vo_detect_fast", "vo_get_features", "vo_set_features",
     "vo_match_klt", "vo_get_matches", "vo_get_klt_legs", "vo_set_matches", "vo_triangulate", "vo_get_object_points",
     "vo_pnp_score", "vo_estimate_motion", "vo_integrate_pose", "vo_step", "vo_step_submit", "vo_step_finish", "vo_read_tap", "vo_pyramid_info",
     "vo_set_timing", "vo_get_timing", "vo_stage_name",
@@ -198,6 +198,20 @@ class Context:
         out = np.empty((self.H, self.W), dtype=np.float64)
         self._check(self._L.vo_get_depth(self._h, b, _ptr(out)))
         return out
+
+    def set_disparity32(self, disp, b=0):
+        """Caller-supplied float disparity map for frame b (what computeDepthMap's argument holds)."""
+        disp = np.ascontiguousarray(disp, dtype=np.float32)
+        if disp.shape != (self.H, self.W):
+            raise ValueError("disparity map shape mismatch")
+        self._check(self._L.vo_set_disparity32(self._h, b, _ptr(disp)))
+
+    def set_depth(self, depth, b=0):
+        """Caller-supplied f64 depth map for frame b (what estimateMotion's depthMap argument holds)."""
+        depth = np.ascontiguousarray(depth, dtype=np.float64)
+        if depth.shape != (self.H, self.W):
+            raise ValueError("depth map shape mismatch")
+        self._check(self._L.vo_set_depth(self._h, b, _ptr(depth)))
 
     def depth_cloud(self, b=0):
         """The vertices VOClass::writeToPLY lists for frame b's depth map, compacted on the GPU: a structured array with

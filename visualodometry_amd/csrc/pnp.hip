@@ -3,7 +3,7 @@
 // computeError/findInliers step that cv::solvePnPRansac (Source/VOClass.cpp:531) runs once per RANSAC iteration.
 //
 //  triangulate_kernel : one block per frame; depth look-up at the truncated feature position (from the f64
-//                       depth map when it exists, else from the s16 disparity with the same 0 / -1 -> 0.1f
+//                       depth map when it exists, else from the f32 disparity with the same 0 / -1 -> 0.1f
 //                       patch), depth filter, back-projection in f64 narrowed to f32, ordered compaction.
 //  score_kernel       : thread per (hypothesis, correspondence): f64 projection, f32 reprojection error,
 //                       inlier ballot; one atomic add per wavefront.
@@ -16,7 +16,7 @@ namespace {
 struct TriArgs { double fx, fy, cx, cy, fxb; float thresh; int W, H, max_features, use_depth; };
 
 __global__ __launch_bounds__(256) void triangulate_kernel(TriArgs a, const vo_point2f* __restrict__ m1, const vo_point2f* __restrict__ m2,
-                                                          const int* __restrict__ n_match, const int16_t* __restrict__ disp16,
+                                                          const int* __restrict__ n_match, const float* __restrict__ disp32,
                                                           const double* __restrict__ depth, vo_point3f* __restrict__ obj,
                                                           vo_point2f* __restrict__ obj_img, int* __restrict__ n_obj)
 {
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void triangulate_kernel(TriArgs a, const vo_po
                 double dz;
                 if (a.use_depth) dz = depth[b * px + (size_t)iv * a.W + iu];
                 else {
-                    float d = (float)disp16[b * px + (size_t)iv * a.W + iu] * (1.0f / 16.0f);
+                    float d = disp32[b * px + (size_t)iv * a.W + iu];
                     if (d == 0.0f || d == -1.0f) d = 0.1f;
                     dz = a.fxb / (double)d;
                 }
@@ -109,7 +109,7 @@ int launch_triangulate(vo_ctx* c)
     a.thresh = (float)c->p.depth_thresh;
     a.W = c->W; a.H = c->H; a.max_features = c->p.max_features; a.use_depth = c->have_depth ? 1 : 0;
     StageTimer st_(c, VO_ST_TRIANGULATE);
-    hipLaunchKernelGGL(triangulate_kernel, dim3(c->n), dim3(256), 0, c->stream, a, c->m1, c->m2, c->n_match, c->disp16, c->depth,
+    hipLaunchKernelGGL(triangulate_kernel, dim3(c->n), dim3(256), 0, c->stream, a, c->m1, c->m2, c->n_match, c->disp32, c->depth,
                        c->obj, c->obj_img, c->n_obj);
     VO_HIP(c, hipGetLastError());
     return VO_OK;

@@ -22,6 +22,7 @@
 #include "vo_ctx.h"
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 
 namespace {
 
@@ -693,10 +694,14 @@ int run_sgbm(vo_ctx* c)
                         : (int)std::min<size_t>((lds_budget - tile_bytes) / slot_bytes, (size_t)(2 * SH2 + 2));
     const size_t lds = tile_bytes + lds_slots * slot_bytes;
     const void* fn = swc ? reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 5, NCOL>) : reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 0, NCOL>);
-    static bool lds_attr_set[64][2]; // per device: a kernel's attributes belong to the device's copy of the code object
-    if (lds > 48 * 1024 && !lds_attr_set[c->device & 63][swc ? 1 : 0]) {
-        VO_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_attr_set[c->device & 63][swc ? 1 : 0] = true;
+    // The dynamic-LDS ceiling of a kernel belongs to the device's copy of the code object and must cover every launch:
+    // `lds` varies with block_size (the ring slots are capped at block_size + 1), so the attribute is set to the budget
+    // itself (or the tile, if that alone exceeds it), which bounds `lds` for this instantiation, and raised if ever needed.
+    static std::atomic<int> lds_attr[64][2];
+    const int lds_cap = (int)std::max(lds_budget, tile_bytes);
+    if (lds > 48 * 1024 && lds_attr[c->device & 63][swc ? 1 : 0].load(std::memory_order_acquire) < lds_cap) {
+        VO_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_cap));
+        lds_attr[c->device & 63][swc ? 1 : 0].store(lds_cap, std::memory_order_release);
     }
     const int tile_out = TILE_COLS - 2 * SH2;
     const dim3 grid((w1 + tile_out - 1) / tile_out, 4, n), blk(VO_COST_THREADS);
@@ -714,10 +719,10 @@ int run_sgbm(vo_ctx* c)
     }
     { StageTimer st_(c, VO_ST_HPATH_BWD);
     const size_t hp_lds = (size_t)4 * vo_hpath_seg(NP) * (16 * NP + 1) * sizeof(int);
-    static bool hp_attr_set[64];
-    if (hp_lds > 48 * 1024 && !hp_attr_set[c->device & 63]) {
+    static std::atomic<int> hp_attr[64];
+    if (hp_lds > 48 * 1024 && hp_attr[c->device & 63].load(std::memory_order_acquire) < (int)hp_lds) {
         VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&hpath_resolve_kernel<NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hp_lds));
-        hp_attr_set[c->device & 63] = true;
+        hp_attr[c->device & 63].store((int)hp_lds, std::memory_order_release);
     }
     hipLaunchKernelGGL((hpath_resolve_kernel<NP>), dim3((H + 3) / 4, n), dim3(64), hp_lds, c->stream, c->cost, c->agg, w1, D, W, H, c->srows, si,
                        c->stripe_sz, c->P1, c->P2, c->p.wta_simd_lanes, nseg, c->ckpt, c->wta);

@@ -29,6 +29,7 @@ int vo_fail(vo_ctx* c, int code, const char* fmt, ...)
 }
 
 #define CHECK_CTX(c) do { if (!(c)) return VO_ERR_BAD_ARG; } while (0)
+#define NOT_PENDING(c) do { if ((c)->step_pending) return vo_fail((c), VO_ERR_STATE, "a submitted step has not been finished: call vo_step_finish first"); } while (0)
 #define CHECK_B(c, b) do { if ((b) < 0 || (b) >= (c)->n) return vo_fail((c), VO_ERR_BAD_ARG, "frame index %d outside the current batch of %d", (b), (c)->n); } while (0)
 
 extern "C" int vo_default_params(vo_params* p, int width, int height)
@@ -176,7 +177,10 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     CR(dalloc(&c->hyp, B * c->p.ransac_chunk * 12));
     CR(dalloc(&c->hyp_count, B * c->p.ransac_chunk));
     CR(dalloc(&c->hyp_mask, B * c->p.ransac_chunk * F));
-    c->h_stage_bytes = std::max<size_t>(B * F * (sizeof(vo_point3f) + sizeof(vo_point2f)) + B * 64, 1 << 20);
+    // pinned staging: the correspondences of a batch ([B][F] points), later reused for a RANSAC round's hypotheses and
+    // counts ([B][chunk] x (12 doubles + 1 int)); inlier masks ride along when they fit
+    c->h_stage_bytes = std::max<size_t>(std::max<size_t>(B * F * (sizeof(vo_point3f) + sizeof(vo_point2f)) + B * 64,
+                                                         B * (size_t)c->p.ransac_chunk * (12 * sizeof(double) + sizeof(int)) + 512), 1 << 20);
     CR(hipHostMalloc(&c->h_stage, c->h_stage_bytes, hipHostMallocDefault));
     CR(hipHostMalloc((void**)&c->h_counts, 3 * B * sizeof(int), hipHostMallocDefault));
     c->h_nfeat.assign(B, 0); c->h_nmatch.assign(B, 0); c->h_nobj.assign(B, 0);
@@ -265,7 +269,7 @@ static bool frames_packed(const vo_ctx* c, int frames, size_t stride, size_t fra
 extern "C" int vo_set_images(vo_ctx* c, int n, const uint8_t* lt1, const uint8_t* rt1, const uint8_t* lt2, const uint8_t* rt2,
                              size_t stride, size_t frame_stride)
 {
-    CHECK_CTX(c);
+    CHECK_CTX(c); NOT_PENDING(c);
     int rc = check_images(c, n, lt1, rt1, lt2, rt2, stride, frame_stride);
     if (rc) return rc;
     VO_HIP(c, hipSetDevice(c->device));
@@ -289,7 +293,7 @@ extern "C" int vo_set_images(vo_ctx* c, int n, const uint8_t* lt1, const uint8_t
 extern "C" int vo_set_images_device(vo_ctx* c, int n, const uint8_t* lt1, const uint8_t* rt1, const uint8_t* lt2, const uint8_t* rt2,
                                     size_t stride, size_t frame_stride)
 {
-    CHECK_CTX(c);
+    CHECK_CTX(c); NOT_PENDING(c);
     int rc = check_images(c, n, lt1, rt1, lt2, rt2, stride, frame_stride);
     if (rc) return rc;
     c->img[0] = lt1; c->img[1] = rt1; c->img[2] = lt2; c->img[3] = rt2;
@@ -300,7 +304,7 @@ extern "C" int vo_set_images_device(vo_ctx* c, int n, const uint8_t* lt1, const 
 
 extern "C" int vo_set_sequence(vo_ctx* c, int n_pairs, const uint8_t* left, const uint8_t* right, size_t stride, size_t frame_stride)
 {
-    CHECK_CTX(c);
+    CHECK_CTX(c); NOT_PENDING(c);
     int rc = check_images(c, n_pairs, left, right, left, right, stride, frame_stride);
     if (rc) return rc;
     if (frame_stride < stride * c->H) return vo_fail(c, VO_ERR_BAD_ARG, "stride smaller than the frame");
@@ -323,7 +327,7 @@ extern "C" int vo_set_sequence(vo_ctx* c, int n_pairs, const uint8_t* left, cons
 
 extern "C" int vo_set_sequence_device(vo_ctx* c, int n_pairs, const uint8_t* left, const uint8_t* right, size_t stride, size_t frame_stride)
 {
-    CHECK_CTX(c);
+    CHECK_CTX(c); NOT_PENDING(c);
     int rc = check_images(c, n_pairs, left, right, left, right, stride, frame_stride);
     if (rc) return rc;
     if (frame_stride < stride * c->H) return vo_fail(c, VO_ERR_BAD_ARG, "stride smaller than the frame");
@@ -344,7 +348,7 @@ static int d2h(vo_ctx* c, void* dst, const void* src, size_t bytes)
 
 extern "C" int vo_compute_disparity(vo_ctx* c)
 {
-    CHECK_CTX(c); NEED_IMAGES(c);
+    CHECK_CTX(c); NOT_PENDING(c); NEED_IMAGES(c);
     VO_HIP(c, hipSetDevice(c->device));
     int rc = launch_sgbm(c);
     if (rc) return rc;
@@ -368,7 +372,7 @@ extern "C" int vo_get_disparity32(vo_ctx* c, int b, float* out)
 
 extern "C" int vo_compute_depth_map(vo_ctx* c)
 {
-    CHECK_CTX(c); NEED_IMAGES(c);
+    CHECK_CTX(c); NOT_PENDING(c); NEED_IMAGES(c);
     if (!c->have_disp) return vo_fail(c, VO_ERR_STATE, "disparity not computed");
     if (!c->have_calib) return vo_fail(c, VO_ERR_STATE, "calibration not set");
     VO_HIP(c, hipSetDevice(c->device));
@@ -383,6 +387,36 @@ extern "C" int vo_get_depth(vo_ctx* c, int b, double* out)
     CHECK_CTX(c); CHECK_B(c, b);
     if (!c->have_depth) return vo_fail(c, VO_ERR_STATE, "depth map not computed");
     return d2h(c, out, c->depth + (size_t)b * c->W * c->H, (size_t)c->W * c->H * sizeof(double));
+}
+
+extern "C" int vo_set_disparity32(vo_ctx* c, int b, const float* disp)
+{
+    CHECK_CTX(c); NOT_PENDING(c); NEED_IMAGES(c); CHECK_B(c, b);
+    if (!disp) return vo_fail(c, VO_ERR_BAD_ARG, "null disparity map");
+    // the other frames of a batch keep their computed maps; without any they have nothing to fall back on
+    if (!c->have_disp && c->n > 1) return vo_fail(c, VO_ERR_STATE, "disparity not computed: a caller-supplied map can replace one frame of a computed batch, or the only frame");
+    VO_HIP(c, hipSetDevice(c->device));
+    VO_HIP(c, hipMemcpyAsync(c->disp32 + (size_t)b * c->W * c->H, disp, (size_t)c->W * c->H * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    c->have_disp = true; c->have_depth = false; c->have_obj = false;
+    return VO_OK;
+}
+
+extern "C" int vo_set_depth(vo_ctx* c, int b, const double* depth)
+{
+    CHECK_CTX(c); NOT_PENDING(c); NEED_IMAGES(c); CHECK_B(c, b);
+    if (!depth) return vo_fail(c, VO_ERR_BAD_ARG, "null depth map");
+    VO_HIP(c, hipSetDevice(c->device));
+    if (!c->have_depth && c->n > 1) {
+        // the other frames of the batch need their own depth maps before the flag can cover the batch
+        if (!c->have_disp || !c->have_calib) return vo_fail(c, VO_ERR_STATE, "depth map not computed: a caller-supplied map can replace one frame of a computed batch, or the only frame");
+        int rc = launch_depth_map(c);
+        if (rc) return rc;
+    }
+    VO_HIP(c, hipMemcpyAsync(c->depth + (size_t)b * c->W * c->H, depth, (size_t)c->W * c->H * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    VO_HIP(c, hipStreamSynchronize(c->stream));
+    c->have_depth = true; c->have_obj = false;
+    return VO_OK;
 }
 
 extern "C" int vo_get_depth_cloud(vo_ctx* c, int b, vo_cloud_point* out, int cap, int* n_out)
@@ -410,7 +444,7 @@ static int fetch_counts(vo_ctx* c, const int* dev, std::vector<int>& host)
 
 extern "C" int vo_detect_fast(vo_ctx* c)
 {
-    CHECK_CTX(c); NEED_IMAGES(c);
+    CHECK_CTX(c); NOT_PENDING(c); NEED_IMAGES(c);
     VO_HIP(c, hipSetDevice(c->device));
     int rc = launch_fast(c);
     if (rc) return rc;
@@ -433,7 +467,7 @@ extern "C" int vo_get_features(vo_ctx* c, int b, vo_point2f* out, int cap, int* 
 
 extern "C" int vo_set_features(vo_ctx* c, int b, const vo_point2f* pts, int n)
 {
-    CHECK_CTX(c); CHECK_B(c, b);
+    CHECK_CTX(c); NOT_PENDING(c); CHECK_B(c, b);
     if (n < 0 || n > c->p.max_features || (n > 0 && !pts)) return vo_fail(c, VO_ERR_BAD_ARG, "feature count %d outside [0, %d]", n, c->p.max_features);
     VO_HIP(c, hipSetDevice(c->device));
     if (n > 0) VO_HIP(c, hipMemcpyAsync(c->feat + (size_t)b * c->p.max_features, pts, (size_t)n * sizeof(vo_point2f), hipMemcpyHostToDevice, c->stream));
@@ -446,7 +480,7 @@ extern "C" int vo_set_features(vo_ctx* c, int b, const vo_point2f* pts, int n)
 
 extern "C" int vo_match_klt(vo_ctx* c)
 {
-    CHECK_CTX(c); NEED_IMAGES(c);
+    CHECK_CTX(c); NOT_PENDING(c); NEED_IMAGES(c);
     if (!c->have_features) return vo_fail(c, VO_ERR_STATE, "no features: call vo_detect_fast or vo_set_features");
     VO_HIP(c, hipSetDevice(c->device));
     int rc;
@@ -486,7 +520,7 @@ extern "C" int vo_get_klt_legs(vo_ctx* c, int b, vo_point2f* pts, uint8_t* statu
 
 extern "C" int vo_set_matches(vo_ctx* c, int b, const vo_point2f* t1, const vo_point2f* t2, int m)
 {
-    CHECK_CTX(c); CHECK_B(c, b);
+    CHECK_CTX(c); NOT_PENDING(c); CHECK_B(c, b);
     if (m < 0 || m > c->p.max_features || (m > 0 && (!t1 || !t2))) return vo_fail(c, VO_ERR_BAD_ARG, "match count %d outside [0, %d]", m, c->p.max_features);
     VO_HIP(c, hipSetDevice(c->device));
     const size_t F = c->p.max_features;
@@ -503,9 +537,9 @@ extern "C" int vo_set_matches(vo_ctx* c, int b, const vo_point2f* t1, const vo_p
 
 extern "C" int vo_triangulate(vo_ctx* c)
 {
-    CHECK_CTX(c); NEED_IMAGES(c);
+    CHECK_CTX(c); NOT_PENDING(c); NEED_IMAGES(c);
     if (!c->have_matches) return vo_fail(c, VO_ERR_STATE, "matches not computed");
-    if (!c->have_disp) return vo_fail(c, VO_ERR_STATE, "disparity not computed");
+    if (!c->have_disp && !c->have_depth) return vo_fail(c, VO_ERR_STATE, "neither a disparity nor a depth map is present");
     if (!c->have_calib) return vo_fail(c, VO_ERR_STATE, "calibration not set");
     VO_HIP(c, hipSetDevice(c->device));
     int rc = launch_triangulate(c);
@@ -569,7 +603,7 @@ extern "C" int vo_integrate_pose(double pose[16], const double Rt[16])
 
 extern "C" int vo_estimate_motion(vo_ctx* c, double* Rt_out, vo_frame_info* info)
 {
-    CHECK_CTX(c); NEED_IMAGES(c);
+    CHECK_CTX(c); NOT_PENDING(c); NEED_IMAGES(c);
     if (!Rt_out) return vo_fail(c, VO_ERR_BAD_ARG, "null output");
     if (!c->have_obj) { int rc = vo_triangulate(c); if (rc) return rc; }
     return pnp_host::estimate_motion_batch(c, Rt_out, info);

@@ -26,8 +26,6 @@ class VOClass:
         self.poseRt = np.eye(4, dtype=np.float64)
         self.projectionCL = np.zeros((3, 4))
         self.projectionCR = np.zeros((3, 4))
-        self._images_key = None
-        self._disp_key = None
 
     # state that getProjectionMatrices (Source/VOClass.cpp:102) fills from calib.txt
     def setProjectionMatrices(self, P0, P1):
@@ -36,27 +34,24 @@ class VOClass:
         self.ctx.set_calib(self.projectionCL, self.projectionCR)
 
     def _sync_images(self, lt1=None, rt1=None):
+        """Uploads the images a method is about to work on.  Always: the reference re-reads its cv::Mat arguments and
+        members on every call, so a caller that refills the same arrays in place must see the new pixels used."""
         lt1 = self.imgLT1 if lt1 is None else lt1
         rt1 = self.imgRT1 if rt1 is None else rt1
         lt2 = self.imgLT2 if self.imgLT2 is not None else lt1
         rt2 = self.imgRT2 if self.imgRT2 is not None else rt1
-        key = tuple(id(a) for a in (lt1, rt1, lt2, rt2))
-        if key != self._images_key:
-            self.ctx.set_images(lt1, rt1, lt2, rt2)
-            self._images_key = key
-            self._disp_key = None
+        self.ctx.set_images(lt1, rt1, lt2, rt2)
 
     def computeDisparity(self, leftImg, rightImg):
         self._sync_images(leftImg, rightImg)
         self.ctx.compute_disparity()
-        self._disp_key = self._images_key
         return self.ctx.disparity32(0)
 
     def computeDepthMap(self, disparityMap):
-        if self._disp_key is None:
-            raise abi.VoError(-5, "computeDisparity has not run on the current images")
+        # the reference converts the map it is handed (Source/VOClass.cpp:312-366), whatever produced it
+        self.ctx.set_disparity32(disparityMap, 0)
         self.ctx.compute_depth_map()
-        # the reference patches the caller's map in place (shared cv::Mat header)
+        # ... and patches the caller's map in place (shared cv::Mat header)
         disparityMap[(disparityMap == 0.0) | (disparityMap == -1.0)] = np.float32(0.1)
         return self.ctx.depth(0)
 
@@ -81,6 +76,8 @@ class VOClass:
     def estimateMotion(self, featurePointsT1, featurePointsT2, depthMap=None):
         assert len(featurePointsT1) == len(featurePointsT2)
         self.ctx.set_matches(featurePointsT1, featurePointsT2, 0)
+        if depthMap is not None:   # the reference looks depths up in the map it is handed (Source/VOClass.cpp:418)
+            self.ctx.set_depth(depthMap, 0)
         self.ctx.triangulate()
         Rt, info = self.ctx.estimate_motion()
         self.lastInfo = info[0]
