@@ -72,6 +72,13 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise OSError("%s not found: build it with `make -C visualodometry_amd/csrc` (python __graft_entry__.py)" % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64, and a process
+        # that first loads the system copy (through this library) and later torch's finds no device from torch.  Loading
+        # torch's copy first makes libvo_amd.so bind to the same runtime, so device pointers and streams can be shared.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         L.vo_last_error.restype = C.c_char_p
         L.vo_create_error.restype = C.c_char_p
