@@ -157,6 +157,16 @@ int vo_get_features(vo_ctx* ctx, int b, vo_point2f* out, int cap, int* n_out);
 /* caller-supplied feature list for frame b (the vector argument of matchFeatureKLT) */
 int vo_set_features(vo_ctx* ctx, int b, const vo_point2f* pts, int n);
 
+/* FAST corners of ONE image, allocating nothing.  No counterpart in the reference: it exists for callers that cannot
+ * allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same
+ * kernels and same results as vo_detect_fast + vo_get_features; the kernels' scratch (score map, row counts, row offsets)
+ * lives in a fixed device array of the library instead of a context, so the image is limited to 2^21 pixels and 4096
+ * rows (VO_ERR_CAPACITY beyond; the text is in vo_create_error()).  img_dev, out_dev (cap points) and n_out_dev (one int:
+ * min(number of corners, cap)) are device pointers on the CURRENT device; the work is enqueued on `stream` (a hipStream_t,
+ * may be NULL) and not waited for.  All calls on one GPU share that GPU's scratch: calls that overlap on one GPU race. */
+int vo_detect_fast_noalloc(const uint8_t* img_dev, int width, int height, size_t stride, int threshold, int nms,
+                           vo_point2f* out_dev, int cap, int* n_out_dev, void* stream);
+
 /* VOClass::matchFeatureKLT (Source/VOClassFeatures.cpp:54-202): four pyramidal LK legs
  * LT1->RT1->RT2->LT2->LT1, bounds filter, 4-way status AND, loop-closure test.
  * t1 receives the re-tracked LT1 points (the reference overwrites its in/out argument with them),

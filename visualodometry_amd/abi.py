@@ -21,7 +21,7 @@ EXPORTS = (
     "vo_default_params", "vo_create", "vo_destroy", "vo_last_error", "vo_create_error", "vo_stream", "vo_synchronize",
     "vo_set_calib", "vo_set_images", "vo_set_images_device", "vo_set_sequence", "vo_set_sequence_device",
     "vo_compute_disparity", "vo_get_disparity16",
-    "vo_get_disparity32", "vo_compute_depth_map", "vo_get_depth", "vo_set_disparity32", "vo_set_depth", "vo_get_depth_cloud", "vo_detect_fast", "vo_get_features", "vo_set_features",
+    "vo_get_disparity32", "vo_compute_depth_map", "vo_get_depth", "vo_set_disparity32", "vo_set_depth", "vo_get_depth_cloud", "vo_detect_fast", "vo_get_features", "vo_set_features", "vo_detect_fast_noalloc",
     "vo_match_klt", "vo_get_matches", "vo_get_klt_legs", "vo_set_matches", "vo_triangulate", "vo_get_object_points",
     "vo_pnp_score", "vo_estimate_motion", "vo_integrate_pose", "vo_step", "vo_step_submit", "vo_step_finish", "vo_read_tap", "vo_pyramid_info",
     "vo_set_timing", "vo_get_timing", "vo_stage_name",
@@ -90,6 +90,7 @@ def lib():
         for name in ("vo_set_sequence", "vo_set_sequence_device"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
         L.vo_read_tap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.vo_detect_fast_noalloc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.vo_pnp_score.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         _LIB = L
     return _LIB

@@ -12,6 +12,7 @@
 #include "vo_ctx.h"
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 
 namespace {
 
@@ -184,5 +185,58 @@ int launch_fast(vo_ctx* c)
     hipLaunchKernelGGL(fast_write_kernel, dim3(H, n), dim3(256), 0, c->stream, c->score, W, H, c->p.fast_nms,
                        c->p.max_features, c->row_count, c->row_off, c->feat);
     VO_HIP(c, hipGetLastError());
+    return VO_OK;
+}
+
+// ---------------------------------------------------------------- detection without any allocation
+// The same four kernels on one image, with their scratch (score map, per-row counts and offsets) in a fixed array of the
+// code object instead of a context's hipMalloc'ed buffers.  Every GPU the library runs on holds its own copy of the array
+// until the process ends.  In host code the array's name is only a handle for hipGetSymbolAddress: the address the
+// kernels get is looked up once per device, with that device current, and kept.
+constexpr size_t kNoAllocMaxPixels = (size_t)1 << 21;   // 2 Mi pixels (e.g. 1920 x 1080); KITTI frames are 0.47 Mi
+constexpr int kNoAllocMaxRows = 4096;
+constexpr size_t kNoAllocScoreBytes = kNoAllocMaxPixels;
+constexpr size_t kNoAllocBytes = kNoAllocScoreBytes + 2 * (size_t)kNoAllocMaxRows * sizeof(int);
+static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
+
+static std::mutex g_scratch_mu;
+static unsigned char* g_scratch_ptr[64]; // per device: address of that device's copy of `scratch`
+
+extern "C" int vo_detect_fast_noalloc(const uint8_t* img_dev, int width, int height, size_t stride, int threshold, int nms,
+                                      vo_point2f* out_dev, int cap, int* n_out_dev, void* stream)
+{
+    if (!img_dev || !out_dev || !n_out_dev || cap < 1) return vo_fail(nullptr, VO_ERR_BAD_ARG, "null pointer or non-positive capacity");
+    if (width < 7 || height < 7 || stride < (size_t)width) return vo_fail(nullptr, VO_ERR_BAD_ARG, "image %dx%d (stride %zu) is not a valid frame", width, height, stride);
+    if ((size_t)width * height > kNoAllocMaxPixels || height > kNoAllocMaxRows)
+        return vo_fail(nullptr, VO_ERR_CAPACITY, "image %dx%d exceeds the fixed scratch of the allocation-free entry point (%zu pixels, %d rows)",
+                       width, height, kNoAllocMaxPixels, kNoAllocMaxRows);
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return vo_fail(nullptr, VO_ERR_NO_DEVICE, "no current HIP device");
+    unsigned char* base;
+    {
+        std::lock_guard<std::mutex> lk(g_scratch_mu);
+        if (!g_scratch_ptr[dev]) {
+            void* p = nullptr;
+            const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !p) return vo_fail(nullptr, VO_ERR_HIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+            g_scratch_ptr[dev] = static_cast<unsigned char*>(p);
+        }
+        base = g_scratch_ptr[dev];
+    }
+    uint8_t* score = base;
+    int* row_count = reinterpret_cast<int*>(base + kNoAllocScoreBytes);
+    int* row_off = row_count + kNoAllocMaxRows;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    threshold = std::min(std::max(threshold, 0), 255);
+    // every word of the scratch that a kernel reads was written by an earlier kernel of this same call (the score kernel
+    // writes all width x height scores, the count kernel all `height` counts, the scan all offsets), so nothing has to
+    // start at zero and what the previous call left behind is never seen
+    dim3 g1((width + TILE_W - 1) / TILE_W, (height + TILE_H - 1) / TILE_H, 1), b1(TILE_W, 4);
+    hipLaunchKernelGGL(fast_score_kernel, g1, b1, 0, st, img_dev, stride, (size_t)0, width, height, threshold, nms, score);
+    hipLaunchKernelGGL(fast_count_kernel, dim3(height, 1), dim3(256), 0, st, score, width, height, nms, row_count);
+    hipLaunchKernelGGL(fast_scan_kernel, dim3(1), dim3(256), 0, st, row_count, height, cap, row_off, n_out_dev);
+    hipLaunchKernelGGL(fast_write_kernel, dim3(height, 1), dim3(256), 0, st, score, width, height, nms, cap, row_count, row_off, out_dev);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return vo_fail(nullptr, VO_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return VO_OK;
 }
