@@ -1,17 +1,31 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the stereo front-end hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--batch B] [--workload kitti|4k]
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--workload kitti|4k|kitti11]
 
 One "step" = one pass of the whole per-frame hot path (disparity, FAST, circular KLT, triangulation,
 PnP-RANSAC; one iteration of the reference's main loop, Source/main.cpp:36-60) over a batch of B independent
-synthetic stereo frame pairs that are already resident in HBM.  Rank r of an N-GPU run works on its own
-sequence (seed 1000 + r): independent units, no collective inside the path; the relative poses are gathered
+synthetic stereo frame pairs that are already resident in HBM.
+
+Workloads
+  kitti, 4k   weak scaling: every rank streams its own rendered sequence (seed 1000 + rank) through K steps of B
+              consecutive frame pairs; no pair repeats inside a batch or between the batches in flight.
+  kitti11     strong scaling, the 11 KITTI 00-10-shaped sequences (4541 ... 1201 frames): whole sequences are dealt
+              to ranks longest-first (sequence.assign_sequences), or with --chunked the steps of all sequences are
+              cut into equal contiguous ranges (sequence.assign_chunks); value = all steps / slowest rank's time.
+Independent units, no collective inside the path; the relative poses (and the last batch's point clouds) are gathered
 once at the end with RCCL.  Prints ONE JSON line on rank 0.
+
+Ranks: under a launcher (torchrun) RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment.  Without one,
+`--gpus N` with N > 1 makes this process start N children itself (one per GPU, before anything here touches a GPU) and
+relay rank 0's line.
 """
 import argparse
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,18 +35,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+KITTI_SEQ_LENGTHS = (4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201)
+METRIC = "stereo frames/sec at 1241x376 (1/2/4/8 GPU) + achieved HBM GB/s vs roofline"
+# what bounds each kernel that has a byte model: the HBM roofline is read against the longest
+# kernel of the "hbm" class; the tracker is bound by vector-instruction issue and is reported beside it
+KERNEL_BOUND = {"sgbm_prefilter": "hbm", "sgbm_cost_vpath": "hbm", "sgbm_hpath_ckpt": "hbm", "sgbm_hpath_resolve": "hbm",
+                "sgbm_lrcheck": "hbm", "sgbm_median": "hbm", "lk": "valu"}
 
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def workload_shape(name):
-    if name == "kitti":
-        return dict(width=1241, height=376, num_disparities=96, lk_win=15, max_features=16384)
-    if name == "4k":
-        return dict(width=3840, height=2160, num_disparities=256, lk_win=15, max_features=65536)
-    raise ValueError(name)
+def workload_shape(name, args):
+    if name in ("kitti", "kitti11"):
+        s = dict(width=1241, height=376, num_disparities=96, lk_win=15, max_features=16384)
+    elif name == "4k":
+        s = dict(width=3840, height=2160, num_disparities=256, lk_win=15, max_features=65536)
+    else:
+        raise ValueError(name)
+    if args.width:
+        s["width"] = args.width
+    if args.height:
+        s["height"] = args.height
+    if args.disparities:
+        s["num_disparities"] = args.disparities
+    return s
 
 
 def stripe_rows(H, block=11):
@@ -53,7 +81,6 @@ def pyramid_pixels(W, H, levels=4):
 def kernel_bytes(W, H, D, srows, nframes):
     """Compulsory (algorithmic) bytes each kernel moves per launch: every input and output counted once."""
     w1 = W - D
-    vol_s = srows * w1 * D * 2      # one per-stripe-row s16 volume (cost, path sums)
     P = W * H
     pyr = pyramid_pixels(W, H)
     vol_h = H * w1 * D * 2          # the rows of a volume that produce output (no stripe warm-up rows)
@@ -80,6 +107,114 @@ def frame_bytes(W, H, D, n_feat=4000):
     a_io = 2 * P + (2 * P + 2 * P) + (P + 8 * n_feat) + 2 * pyr + 2 * (pyr + 4 * pyr) + 4 * (pyr + 4 * pyr + pyr)
     a_cv = 2 * 2 * C
     return a_io + a_cv
+
+
+# ------------------------------------------------------------------ rendering (host, before any GPU use)
+def _render_one(job):
+    from visualodometry_amd import synth
+    seed, W, H, i = job
+    return synth.Sequence(seed=seed, width=W, height=H).frame(i)
+
+
+def render_frames(seed, W, H, count, workers):
+    """`count` consecutive stereo frames of the synthetic sequence `seed`, rendered on `workers` host processes."""
+    jobs = [(seed, W, H, i) for i in range(count)]
+    if workers <= 1 or count <= 2:
+        return [_render_one(j) for j in jobs]
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(min(workers, count)) as pool:   # forked before this process touches a GPU
+        return pool.map(_render_one, jobs, chunksize=1)
+
+
+# ------------------------------------------------------------------ self-launch of N ranks
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args, argv):
+    """Parent of an N-rank run without an outside launcher: starts N children (fresh processes, one per GPU) and relays
+    rank 0's JSON line.  This process never initialises a GPU."""
+    n = args.gpus
+    env0 = dict(os.environ)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0["MASTER_PORT"] = str(free_port())
+    env0["WORLD_SIZE"] = str(n)
+    env0["LOCAL_WORLD_SIZE"] = str(n)
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        env = dict(env0)
+        env["RANK"] = env["LOCAL_RANK"] = str(r)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    for line in out0.splitlines():   # the result line goes to stdout, anything a library printed there to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        log("[bench] ranks failed: %s" % bad)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------ plumbing stand-in for the multi-rank tests
+class StubContext:
+    """NOT a compute path: stands in for abi.Context in the multi-process plumbing test of this file (--stub-context), on
+    machines without a GPU.  'Poses' are a deterministic function of the frames a step was handed (their byte sums), so the
+    test can tell that every rank processed the frames it was assigned and that the gather put them in order."""
+
+    def __init__(self, W, H, B):
+        self.W, self.H, self.B, self.n = W, H, B, 0
+        self._ptrs = None
+
+    def set_calib(self, P0, P1):
+        pass
+
+    def set_images_device(self, n, ptrs, stride, frame_stride, keep=None):
+        self.n, self._ptrs, self._fs, self._keep = n, [ptrs[0], ptrs[2]], frame_stride, keep
+
+    def set_sequence_device(self, n, left, right, stride, frame_stride, keep=None):
+        self.n, self._ptrs, self._fs, self._keep = n, [left, left + frame_stride], frame_stride, keep
+
+    @staticmethod
+    def pose_of(a_sum, b_sum):
+        Rt = np.eye(4)
+        Rt[:3, 3] = [(a_sum % 100003) * 1e-5, (b_sum % 100003) * 1e-5, -0.8]
+        return Rt
+
+    def _frame_sum(self, ptr):
+        buf = (ctypes.c_uint8 * (self.W * self.H)).from_address(ptr)
+        return int(np.frombuffer(buf, dtype=np.uint8).astype(np.int64).sum())
+
+    def step_submit(self):
+        pass
+
+    def step_finish(self, strict=True):
+        Rt = np.stack([self.pose_of(self._frame_sum(self._ptrs[0] + b * self._fs), self._frame_sum(self._ptrs[1] + b * self._fs))
+                       for b in range(self.n)])
+        info = [argparse.Namespace(n_features=0, n_matched=0, ok=1) for _ in range(self.n)]
+        return Rt, info
+
+    def step(self, strict=True):
+        return self.step_finish()
+
+    def object_points(self, b=0):
+        return np.zeros((1, 3), dtype=np.float32), np.zeros((1, 2), dtype=np.float32)
+
+    def synchronize(self):
+        pass
+
+    def set_timing(self, enable=True):
+        pass
+
+    def timing(self, reset=False):
+        return {}
 
 
 def cpu_baseline(frames, seq, shape, sample_pairs):
@@ -111,14 +246,18 @@ def cpu_baseline(frames, seq, shape, sample_pairs):
             "single_thread_value": n1 / dt1, "single_thread_sample": "%d frame pairs, %.1f s wall" % (n1, dt1)}
 
 
-def main():
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="frame pairs per step (default: 16 at KITTI shape, 8 at 4K)")
-    ap.add_argument("--workload", default="kitti", choices=["kitti", "4k"])
-    ap.add_argument("--distinct", type=int, default=4, help="distinct frame pairs rendered (tiled to fill the batch)")
+    ap.add_argument("--workload", default="kitti", choices=["kitti", "4k", "kitti11"])
+    ap.add_argument("--frames", type=int, default=0,
+                    help="consecutive frames rendered per rank and kept in HBM (default: one window of `batch` pairs per batch in "
+                         "flight, plus one; 200 = the whole sequence of the single-GPU configuration)")
+    ap.add_argument("--chunked", action="store_true", help="kitti11: contiguous step ranges per rank instead of whole sequences")
+    ap.add_argument("--scale", type=float, default=1.0, help="kitti11: scale every sequence length (rehearsals, tests)")
     ap.add_argument("--cpu-pairs", type=int, default=12)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0)
@@ -126,170 +265,320 @@ def main():
                     help="contexts taking turns (overlaps host PnP with GPU work; default: 3 at KITTI shape, 2 at 4K, "
                          "where a context holds 5.5 GB per frame pair)")
     ap.add_argument("--upload", action="store_true",
-                    help="re-upload the batch's images from host memory before every step (PCIe-inclusive rate; the headline "
-                         "value is measured without it, inputs resident in HBM)")
+                    help="re-upload the batch's images from host memory before every step of the timed region (PCIe-inclusive rate; "
+                         "the headline value is measured without it, inputs resident in HBM)")
+    ap.add_argument("--no-upload-leg", action="store_true", help="skip the second, upload-inclusive timed pass (config.value_with_upload)")
     ap.add_argument("--latency", action="store_true",
                     help="also time one frame pair alone (batch of 1) after the run; off by default so that a kernel profile "
                          "of the default command holds launches of one batch size only")
     ap.add_argument("--mode", default="pairs", choices=["pairs", "sequence"],
                     help="pairs: B independent frame pairs, 4 pyramids each (what the reference rebuilds per step); "
                          "sequence: B + 1 consecutive frames, every frame pyramided once")
-    args = ap.parse_args()
+    ap.add_argument("--rehearse", action="store_true",
+                    help="more ranks than GPUs: rank r uses GPU r mod (GPUs present) and the gather runs over gloo (plumbing rehearsal)")
+    ap.add_argument("--stub-context", action="store_true", help="plumbing test without a GPU: no kernels run, the value is meaningless")
+    ap.add_argument("--dump-poses", default="", help="rank 0 writes the gathered relative poses to this .npz file")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--disparities", type=int, default=0)
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args, argv)
     if args.batch <= 0:
         args.batch = 8 if args.workload == "4k" else 16
     if args.inflight <= 0:
         args.inflight = 2 if args.workload == "4k" else 3
 
-    import torch
-    import torch.distributed as dist
-    from visualodometry_amd import abi, synth
-
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if "VO_BENCH_DEVICE" in os.environ:  # rehearsal of the multi-rank path on a box with fewer GPUs than ranks
-        local_rank = int(os.environ["VO_BENCH_DEVICE"])
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    # host threads: one pool per process, sized to this rank's share of the node's cores
+    cpu_share = max(1, min(16, (os.cpu_count() or 1) // max(local_world, 1)))
+    if args.host_threads <= 0:
+        args.host_threads = cpu_share
+
+    shape = workload_shape(args.workload, args)
+    W, H, D = shape["width"], shape["height"], shape["num_disparities"]
+    B = args.batch
+    nctx = max(1, args.inflight)
+    strong = args.workload == "kitti11"
+
+    # ---- input: rendered on the host before the GPU is touched (the worker pool is forked)
+    from visualodometry_amd import synth
+    seq_seed = 1000 if strong else 1000 + rank
+    seq = synth.Sequence(seed=seq_seed, width=W, height=H)
+    nframes = args.frames if args.frames > 0 else nctx * B + 1
+    nframes = max(nframes, B + 1)
+    t0 = time.perf_counter()
+    frames = render_frames(seq_seed, W, H, nframes, cpu_share)
+    log("[rank %d] rendered %d synthetic %dx%d stereo frames in %.1f s on %d host processes" % (rank, nframes, W, H, time.perf_counter() - t0, cpu_share))
+
+    import torch
+    import torch.distributed as dist
+    stub = args.stub_context
+    if not stub:
+        from visualodometry_amd import abi
+        ndev = torch.cuda.device_count()
+        if ndev < 1:
+            raise SystemExit("bench.py needs a GPU")
+        if local_world > ndev and not args.rehearse:
+            raise SystemExit("bench.py: %d ranks on this node but %d GPUs (use --rehearse to share GPUs in a plumbing rehearsal)" % (local_world, ndev))
+        device_index = local_rank % ndev
+    backend = "gloo" if (stub or args.rehearse) else "nccl"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # RCCL ("nccl") is the backend of a real run; gloo only for rehearsing the multi-rank flow on one GPU
-        backend = os.environ.get("VO_BENCH_BACKEND", "nccl")
+        # RCCL ("nccl") is the backend of a real run; gloo only for rehearsing the multi-rank flow
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    shape = workload_shape(args.workload)
-    W, H, D = shape["width"], shape["height"], shape["num_disparities"]
-    B = args.batch
-    seq = synth.Sequence(seed=1000 + rank, width=W, height=H)
-    nd = max(1, min(args.distinct, B))
-    t0 = time.perf_counter()
-    frames = [seq.frame(i) for i in range(nd + 1)]
-    log("[rank %d] rendered %d synthetic frames in %.1f s" % (rank, nd + 1, time.perf_counter() - t0))
-
-    def tiled(which, shift):
-        arr = np.stack([frames[(b % nd) + shift][which] for b in range(B)])
-        return torch.from_numpy(arr).to(dev)
-
-    if args.mode == "pairs":
-        lt1, rt1, lt2, rt2 = tiled(0, 0), tiled(1, 0), tiled(0, 1), tiled(1, 1)  # resident in HBM before timing starts
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    if stub:
+        dev = torch.device("cpu")
     else:
-        # B + 1 consecutive frames: walk the rendered frames forth and back so that every pair is a real motion
-        walk = [m if m <= nd else 2 * nd - m for m in (k % (2 * nd) for k in range(B + 1))]
-        left = torch.from_numpy(np.stack([frames[w][0] for w in walk])).to(dev)
-        right = torch.from_numpy(np.stack([frames[w][1] for w in walk])).to(dev)
+        torch.cuda.set_device(device_index)
+        dev = torch.device("cuda", device_index)
 
-    p = abi.default_params(W, H, max_batch=B, num_disparities=D, lk_win=shape["lk_win"], max_features=shape["max_features"],
-                           host_threads=args.host_threads)
-    # `inflight` contexts take turns: while the host part (minimal solvers, refine) of one batch runs, the GPU
-    # part of the next batch is already enqueued on the other context's stream
-    ctxs = []
-    for _ in range(max(1, args.inflight)):
-        c = abi.Context(p, local_rank)
+    def dev_sync():
+        if not stub:
+            torch.cuda.synchronize()
+
+    # the whole rendered sequence lives in HBM: [nframes][H][W] per camera
+    left = torch.from_numpy(np.stack([f[0] for f in frames])).to(dev)
+    right = torch.from_numpy(np.stack([f[1] for f in frames])).to(dev)
+    FS = W * H
+
+    if stub:
+        ctxs = [StubContext(W, H, B) for _ in range(nctx)]
+    else:
+        p = abi.default_params(W, H, max_batch=B, num_disparities=D, lk_win=shape["lk_win"], max_features=shape["max_features"],
+                               host_threads=args.host_threads)
+        ctxs = [abi.Context(p, device_index) for _ in range(nctx)]
+    for c in ctxs:
         c.set_calib(seq.P0, seq.P1)
-        if args.mode == "pairs":
-            c.set_images_device(B, [t.data_ptr() for t in (lt1, rt1, lt2, rt2)], W, W * H, keep=(lt1, rt1, lt2, rt2))
-        else:
-            c.set_sequence_device(B, left.data_ptr(), right.data_ptr(), W, W * H, keep=(left, right))
-        ctxs.append(c)
     ctx = ctxs[0]
-    nctx = len(ctxs)
 
-    host_imgs = None
-    if args.upload:
+    def set_window(c, lptr, rptr, n):
+        """n consecutive frame pairs starting at the frames lptr / rptr point to (device memory, frames FS bytes apart)"""
         if args.mode == "pairs":
-            host_imgs = [t.cpu().numpy() for t in (lt1, rt1, lt2, rt2)]
+            c.set_images_device(n, [lptr, rptr, lptr + FS, rptr + FS], W, FS, keep=(left, right))
         else:
-            host_imgs = [left.cpu().numpy(), right.cpu().numpy()]
+            c.set_sequence_device(n, lptr, rptr, W, FS, keep=(left, right))
 
-    def submit(c):
-        if host_imgs is not None:   # host -> device copy of the whole batch, then the step
+    # ---- weak-scaling workload: K steps over windows of the rank's own sequence
+    nwin = (nframes - 1) // B   # disjoint windows of B pairs; batches in flight at the same time use different ones
+    host_left = host_right = None
+
+    def submit_window(c, w, upload):
+        f0 = (w % nwin) * B
+        if upload:   # host -> device copy of the window's frames, then the step
             if args.mode == "pairs":
-                c.set_images(*host_imgs)
+                c.set_images(host_left[f0:f0 + B], host_right[f0:f0 + B], host_left[f0 + 1:f0 + B + 1], host_right[f0 + 1:f0 + B + 1])
             else:
-                c.set_sequence(*host_imgs)
+                c.set_sequence(host_left[f0:f0 + B + 1], host_right[f0:f0 + B + 1])
+        else:
+            set_window(c, left.data_ptr() + f0 * FS, right.data_ptr() + f0 * FS, B)
         c.step_submit()
 
-    def run_steps(k):
-        """k whole batches through the path, pipeline fill and drain included"""
+    def run_steps(k, upload=False):
+        """k whole batches through the path, pipeline fill and drain included; returns the last batch's results"""
         out = None
         for s in range(min(nctx, k)):
-            submit(ctxs[s])
+            submit_window(ctxs[s], s, upload)
         for s in range(k):
             c = ctxs[s % nctx]
             out = c.step_finish()
             if s + nctx < k:
-                submit(c)
+                submit_window(c, s + nctx, upload)
         return out
 
-    if args.warmup > 0:
-        Rt, info = run_steps(args.warmup)
-    for c in ctxs:
-        c.set_timing(True)
-        c.timing(reset=True)
+    # ---- strong-scaling workload: the 11 KITTI-shaped sequences
+    lengths = [max(2, int(round(n * args.scale))) for n in KITTI_SEQ_LENGTHS]
+    from visualodometry_amd import sequence as vseq
+    if strong:
+        if args.chunked:
+            mine = vseq.assign_chunks(lengths, world)[rank]
+            loads = [sum(e - f for _, f, e in ch) for ch in vseq.assign_chunks(lengths, world)]
+        else:
+            owner = vseq.assign_sequences(lengths, world)
+            mine = [(i, 0, lengths[i] - 1) for i in owner[rank]]
+            loads = [sum(lengths[i] - 1 for i in o) for o in owner]
+        period = 2 * (nframes - 1)
+
+        def pool_index(i, t):
+            """frame t of sequence i as an index into the rendered frames: a walk forth and back over them (every pair of
+            consecutive frames is a real camera motion), started at a sequence-dependent phase"""
+            m = (t + 7 * i) % period
+            return m if m <= nframes - 1 else period - m
+        staging = [(torch.empty((B + 1, H, W), dtype=torch.uint8, device=dev), torch.empty((B + 1, H, W), dtype=torch.uint8, device=dev))
+                   for _ in range(nctx)]
+        batches = []   # (sequence, first step, n pairs)
+        for i, first, end in mine:
+            for s in range(first, end, B):
+                batches.append((i, s, min(B, end - s)))
+
+        def submit_batch(k, j):
+            i, s, n = batches[j]
+            pi = [pool_index(i, s + q) for q in range(n + 1)]
+            c = ctxs[k]
+            if pi[-1] - pi[0] == n:   # an ascending run of the rendered frames: used where it lies
+                lp, rp, keep = left.data_ptr() + pi[0] * FS, right.data_ptr() + pi[0] * FS, (left, right)
+            else:                      # the walk turns inside the batch: its n + 1 frames are copied together (device to device)
+                sl, sr = staging[k]
+                idx = torch.tensor(pi, device=dev)
+                torch.index_select(left, 0, idx, out=sl[:n + 1])
+                torch.index_select(right, 0, idx, out=sr[:n + 1])
+                if not stub:
+                    torch.cuda.current_stream().synchronize()   # the context's stream does not wait for torch's
+                lp, rp, keep = sl.data_ptr(), sr.data_ptr(), (sl, sr)
+            if args.mode == "pairs":
+                c.set_images_device(n, [lp, rp, lp + FS, rp + FS], W, FS, keep=keep)
+            else:
+                c.set_sequence_device(n, lp, rp, W, FS, keep=keep)
+            c.step_submit()
+
+        def run_batches(nb):
+            local = {}
+            out = None
+            for j in range(min(nctx, nb)):
+                submit_batch(j % nctx, j)
+            for j in range(nb):
+                out = ctxs[j % nctx].step_finish(strict=False)
+                i, s, n = batches[j]
+                local.setdefault(i, []).append((s, np.asarray(out[0]).reshape(n, 16)))
+                if j + nctx < nb:
+                    submit_batch(j % nctx, j + nctx)
+            return local, out
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    barrier(); torch.cuda.synchronize()
+    # ---- warm-up
+    if args.warmup > 0:
+        if strong:
+            run_batches(min(args.warmup, len(batches)))
+        else:
+            run_steps(args.warmup)
+    for c in ctxs:
+        c.set_timing(True)
+        c.timing(reset=True)
+
+    # ---- timed region
+    cdev = dev if (world == 1 or backend == "nccl") else torch.device("cpu")
+    if args.upload:
+        host_left, host_right = left.cpu().numpy(), right.cpu().numpy()
+    barrier(); dev_sync()
     for c in ctxs:
         c.synchronize()
     t0 = time.perf_counter()
-    Rt, info = run_steps(args.steps)
-    for c in ctxs:
-        c.synchronize()
-    torch.cuda.synchronize()
-    # the only collective: gather the per-frame relative poses of every rank (result gather, RCCL over xGMI)
-    cdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
-    poses = torch.from_numpy(Rt).to(cdev)
-    if world > 1:
-        gathered = [torch.empty_like(poses) for _ in range(world)]
-        dist.all_gather(gathered, poses)
-        # ... and the point clouds (triangulated points) of the last batch, as fixed-size padded buffers
-        from visualodometry_amd import sequence as vseq
-        last = ctxs[(args.steps - 1) % nctx]
-        clouds = vseq.gather_point_clouds([last.object_points(b)[0] for b in range(B)], cap=shape["max_features"])
-        assert len(clouds) == world
-        torch.cuda.synchronize()
+    gathered_poses = None
+    if strong:
+        local, last = run_batches(len(batches))
+        Rt, info = last if last is not None else (np.zeros((0, 4, 4)), [])
+        for c in ctxs:
+            c.synchronize()
+        dev_sync()
+        t_compute = time.perf_counter() - t0
+        loc = {}
+        for i, parts in local.items():
+            parts.sort(key=lambda x: x[0])
+            loc[i] = (parts[0][0], np.concatenate([a for _, a in parts]))
+        # the only collective: every rank ends up with every sequence's relative poses
+        gathered_poses = vseq.gather_trajectories(loc, len(lengths), max(lengths) - 1)
+        my_steps = sum(n for _, _, n in batches)
+        total_pairs = sum(n - 1 for n in lengths)
+    else:
+        Rt, info = run_steps(args.steps, upload=args.upload)
+        for c in ctxs:
+            c.synchronize()
+        dev_sync()
+        t_compute = time.perf_counter() - t0
+        # the only collective: gather the per-frame relative poses of every rank (result gather, RCCL over xGMI)
+        poses = torch.from_numpy(np.ascontiguousarray(Rt)).to(cdev)
+        if world > 1:
+            gathered = [torch.empty_like(poses) for _ in range(world)]
+            dist.all_gather(gathered, poses)
+            gathered_poses = {r: g.cpu().numpy() for r, g in enumerate(gathered)}
+            # ... and the point clouds (triangulated points) of the last batch, as fixed-size padded buffers
+            lastc = ctxs[(args.steps - 1) % nctx]
+            clouds = vseq.gather_point_clouds([lastc.object_points(b)[0] for b in range(B)], cap=shape["max_features"])
+            assert len(clouds) == world
+            dev_sync()
+        else:
+            gathered_poses = {0: np.asarray(Rt)}
+        my_steps = args.steps * B
+        total_pairs = world * B * args.steps
     barrier()
     dt = time.perf_counter() - t0
+    t_all = [t_compute]
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        tc = torch.tensor([t_compute], dtype=torch.float64, device=cdev)
+        tcs = [torch.empty_like(tc) for _ in range(world)]
+        dist.all_gather(tcs, tc)
+        t_all = [float(t.item()) for t in tcs]
 
     timing = {}
     for c in ctxs:
         for k, v in c.timing().items():
             a = timing.get(k, (0.0, 0))
             timing[k] = (a[0] + v[0], a[1] + v[1])
-    # outside the timed region: the same kernels with one batch in flight, i.e. without other batches' kernels
-    # sharing the GPU, which is the duration a kernel-level roofline should be read against
+
+    # ---- outside the timed region
+    # the same K steps with every window re-uploaded from (pageable) host memory first: the PCIe-inclusive rate
+    value_with_upload = None
+    if not strong and not args.upload and not args.no_upload_leg and not stub:
+        host_left, host_right = left.cpu().numpy(), right.cpu().numpy()
+        run_steps(min(3, args.steps), upload=True)
+        barrier(); dev_sync()
+        tu = time.perf_counter()
+        run_steps(args.steps, upload=True)
+        for c in ctxs:
+            c.synchronize()
+        barrier()
+        tu = time.perf_counter() - tu
+        if world > 1:
+            tm = torch.tensor([tu], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            tu = float(tm.item())
+        value_with_upload = world * B * args.steps / tu
+    # the same kernels with one batch in flight, i.e. without other batches' kernels sharing the GPU, which is the
+    # duration a kernel-level roofline should be read against
     isolated = {}
-    if nctx > 1:
+    if nctx > 1 and not stub:
+        set_window(ctx, left.data_ptr(), right.data_ptr(), B)
         ctx.timing(reset=True)
         for _ in range(3):
             ctx.step()
         isolated = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in ctx.timing().items()}
-    # latency of one frame pair alone (batch of 1, one stream, nothing else in flight), outside the timed region
+    # latency of one frame pair alone (batch of 1, one stream, nothing else in flight)
     latency_ms = None
-    if args.latency and args.mode == "pairs":
-        ctx.set_images_device(1, [t.data_ptr() for t in (lt1, rt1, lt2, rt2)], W, W * H, keep=(lt1, rt1, lt2, rt2))
+    if args.latency and not stub:
+        set_window(ctx, left.data_ptr(), right.data_ptr(), 1)
         for _ in range(2):
             ctx.step()
         tl = time.perf_counter()
         for _ in range(10):
             ctx.step()
         latency_ms = (time.perf_counter() - tl) / 10 * 1e3
+
     if rank == 0:
-        steps = args.steps
-        fps = world * B * steps / dt
+        if strong:
+            got = sum(a.shape[0] for a in gathered_poses.values())
+            assert got == total_pairs, "gathered %d steps, expected %d" % (got, total_pairs)
+        if args.dump_poses:
+            np.savez(args.dump_poses, **{"seq%d" % k: v for k, v in gathered_poses.items()})
+        steps = len(batches) if strong else args.steps
+        fps = total_pairs / dt
         srows = stripe_rows(H)
         kb = kernel_bytes(W, H, D, srows, B)
         stage_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in timing.items()}
@@ -299,13 +588,14 @@ def main():
         # agree with it).  The roofline therefore uses the one-batch-in-flight pass made right after the timed region
         # (same process, same inputs, same HIP-event timers on the kernels' stream); the timed-region figures ride along.
         excl = isolated if isolated else stage_ms
-        dom = max(kb, key=lambda k: excl.get(k, 0.0))
+        hbm_kernels = [k for k in kb if KERNEL_BOUND.get(k) == "hbm"]
+        dom = max(hbm_kernels, key=lambda k: excl.get(k, 0.0))
         achieved = kb[dom] / (excl[dom] * 1e-3) / 1e9 if excl.get(dom, 0) > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(args.workload, {}).get(dom)
+                traffic = json.load(open(tf)).get("4k" if args.workload == "4k" else "kitti", {}).get(dom)
             except Exception:
                 traffic = None
 
@@ -313,9 +603,9 @@ def main():
         # issue capacity = instructions x cycles per instruction / (SIMDs x clock x duration)
         valu = None
         vf = os.path.join(ROOT, "profiles", "valu.json")
-        if os.path.exists(vf):
+        if os.path.exists(vf) and args.workload != "4k":
             try:
-                vj = json.load(open(vf)).get(args.workload, {})
+                vj = json.load(open(vf)).get("kitti", {})
                 valu = {}
                 for k, v in vj.items():
                     if isinstance(v, dict) and excl.get(k, 0) > 0:
@@ -328,42 +618,65 @@ def main():
         def frac(ms, k):
             return round(kb[k] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms.get(k, 0) > 0 else None
 
+        whole_gbs = frame_bytes(W, H, D) * fps / world / 1e9
+        config = {"workload": "%s: synthetic stereo, %dx%d, %d disparities, %d frame pairs per step per GPU, whole hot path "
+                              "(SGBM-3way + FAST + circular KLT + triangulation + PnP-RANSAC)" % (args.workload, W, H, D, B),
+                  "batch": B, "batches_in_flight": nctx, "input_mode": args.mode,
+                  "inputs": "uploaded from host memory every step" if args.upload else "resident in HBM",
+                  "distinct_frames_per_rank": nframes, "host_threads_per_rank": args.host_threads,
+                  "sharding": ("11 KITTI 00-10-shaped sequences (%d steps), %s; relative poses all-gathered once (%s)" %
+                               (total_pairs, "contiguous step ranges per rank" if args.chunked else "whole sequences per rank, longest first",
+                                "RCCL" if backend == "nccl" else "gloo")) if strong else
+                              "independent sequences, one per GPU; poses and the last batch's point clouds all-gathered once (%s)" %
+                              ("RCCL" if backend == "nccl" else "gloo"),
+                  "mpix_per_s": fps * W * H / 1e6, "latency_ms_one_pair_alone": latency_ms,
+                  "value_with_upload": value_with_upload,
+                  "features_per_frame": int(np.mean([i.n_features for i in info])) if len(info) else 0,
+                  "matches_per_frame": int(np.mean([i.n_matched for i in info])) if len(info) else 0,
+                  "stage_ms_timed_region": {k: round(v, 4) for k, v in stage_ms.items()},
+                  "stage_ms_one_batch_in_flight": {k: round(v, 4) for k, v in excl.items()},
+                  "whole_path_algorithmic_GBs": whole_gbs,
+                  "rank_compute_s": [round(t, 4) for t in t_all]}
+        if strong:
+            config["steps_per_rank"] = loads
+            config["imbalance_max_over_mean"] = round(max(loads) / (sum(loads) / len(loads)), 4) if sum(loads) else None
+            config["sequence_lengths"] = lengths
+        if stub:
+            config["stub"] = True
         out = {
-            "metric": "stereo frames/sec at 1241x376 (1/2/4/8 GPU) + achieved HBM GB/s vs roofline",
+            "metric": METRIC,
             "value": fps, "unit": "stereo frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
-            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / max(steps, 1) * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "s16 (disparity, FAST: u8/s16 integer; LK: int32/int64 accumulators + f32 solve; PnP: f64)",
             "data": "synthetic",
-            "config": {"workload": "%s-shape synthetic stereo, %dx%d, %d disparities, %d frame pairs per step per GPU, whole hot path "
-                                   "(SGBM-3way + FAST + circular KLT + triangulation + PnP-RANSAC)" % (args.workload, W, H, D, B),
-                       "batch": B, "batches_in_flight": nctx, "input_mode": args.mode, "inputs": "uploaded from host memory every step" if args.upload else "resident in HBM", "sharding": "independent sequences, one per GPU; poses and the last batch's point clouds all-gathered once (RCCL)",
-                       "mpix_per_s": fps * W * H / 1e6, "latency_ms_one_pair_alone": latency_ms,
-                       "features_per_frame": int(np.mean([i.n_features for i in info])),
-                       "matches_per_frame": int(np.mean([i.n_matched for i in info])),
-                       "stage_ms_timed_region": {k: round(v, 4) for k, v in stage_ms.items()},
-                       "stage_ms_one_batch_in_flight": {k: round(v, 4) for k, v in excl.items()},
-                       "whole_path_algorithmic_GBs": frame_bytes(W, H, D) * fps / world / 1e9},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         # what plain streaming kernels reach on this GPU (tools/micro/hbm_rate.hip, measured once)
-                         "streaming_GBs_measured": {"read": 6290, "write": 3890, "copy": 4450, "1_read_4_writes": 4440},
-                         "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": excl.get(dom, 0.0),
-                         "avg_launch_ms_timed_region": stage_ms.get(dom, 0.0), "frac_timed_region": frac(stage_ms, dom),
-                         "valu_issue": valu,
-                         "measured": "HIP events on the kernel's stream, one batch in flight, right after the timed region"
-                                     if isolated else "HIP events on the kernel's stream over the timed region",
-                         # the tracker and the resolve pass are bound by vector instruction issue, not by HBM: their
-                         # fractions say how far below the memory roof they sit
-                         "per_kernel": {k: {"algorithmic_GB_per_launch": round(kb[k] / 1e9, 4), "avg_launch_ms": round(excl.get(k, 0.0), 4),
-                                            "frac": frac(excl, k), "avg_launch_ms_timed_region": round(stage_ms.get(k, 0.0), 4)} for k in kb}},
+            "config": config,
         }
-        if not args.no_cpu and world == 1:   # the CPU baseline is a single-GPU-run item
+        if not stub:
+            out["roofline"] = {
+                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel_choice": "longest launch among the kernels bound by HBM; the tracker (lk) is bound by vector-instruction issue, "
+                                 "see valu_issue",
+                # the whole path against the same roof: algorithmic bytes per frame x frames/s of one GPU
+                "whole_path": {"algorithmic_GBs": whole_gbs, "frac": whole_gbs / HBM_PEAK_GBS},
+                # what plain streaming kernels reach on this GPU (tools/micro/hbm_rate.hip, measured once)
+                "streaming_GBs_measured": {"read": 6290, "write": 3890, "copy": 4450, "1_read_4_writes": 4440},
+                "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": excl.get(dom, 0.0),
+                "avg_launch_ms_timed_region": stage_ms.get(dom, 0.0), "frac_timed_region": frac(stage_ms, dom),
+                "valu_issue": valu,
+                "measured": "HIP events on the kernel's stream, one batch in flight, right after the timed region"
+                            if isolated else "HIP events on the kernel's stream over the timed region",
+                "per_kernel": {k: {"bound": KERNEL_BOUND.get(k), "algorithmic_GB_per_launch": round(kb[k] / 1e9, 4),
+                                   "avg_launch_ms": round(excl.get(k, 0.0), 4), "frac": frac(excl, k),
+                                   "avg_launch_ms_timed_region": round(stage_ms.get(k, 0.0), 4)} for k in kb}}
+        if not args.no_cpu and world == 1 and not stub:   # the CPU baseline is a single-GPU-run item
             out["cpu_baseline"] = cpu_baseline(frames, seq, shape, args.cpu_pairs)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

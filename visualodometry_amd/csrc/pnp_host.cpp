@@ -569,11 +569,24 @@ public:
     }
 };
 
-void parallel_for(vo_ctx* c, int count, int threads, const std::function<void(int)>& fn)
+// One pool per process, shared by all contexts (a node runs one process per GPU, several contexts per process: a pool per
+// context would multiply the host threads by the batches in flight).  A section that finds the pool busy with another
+// thread's section runs on its own thread instead of waiting.
+std::mutex g_pool_mu;
+Pool* g_pool = nullptr;
+int g_pool_workers = 0;
+
+void parallel_for(vo_ctx*, int count, int threads, const std::function<void(int)>& fn)
 {
     if (threads <= 1 || count <= 1) { for (int i = 0; i < count; i++) fn(i); return; }
-    if (!c->host_pool) c->host_pool = new Pool(threads - 1);
-    static_cast<Pool*>(c->host_pool)->run(count, fn);
+    std::unique_lock<std::mutex> lk(g_pool_mu, std::try_to_lock);
+    if (!lk.owns_lock()) { for (int i = 0; i < count; i++) fn(i); return; }
+    if (!g_pool || g_pool_workers < threads - 1) {
+        delete g_pool;
+        g_pool_workers = threads - 1;
+        g_pool = new Pool(g_pool_workers);
+    }
+    g_pool->run(count, fn);
 }
 
 struct FrameRansac {
@@ -747,8 +760,6 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
     if (status != VO_OK) return vo_fail(c, status, "a frame of the batch has fewer than 5 3D-2D correspondences");
     return VO_OK;
 }
-
-void destroy_pool(void* pool) { delete static_cast<Pool*>(pool); }
 
 // The RANSAC rounds are short host <-> GPU round trips (a few small copies and one scoring kernel each).  They run on
 // the context's high-priority stream so that they do not queue behind the bulk kernels other contexts have in flight.

@@ -31,7 +31,6 @@ int iterative(const double* obj, const double* img, int n, const double K[9], do
 
 // RANSAC + refine for every frame of the current batch; hypotheses are scored by the GPU kernel.
 int estimate_motion_batch(vo_ctx* c, double* Rt_out, vo_frame_info* info);
-void destroy_pool(void* pool); // vo_ctx::host_pool
 
 } // namespace pnp_host
 #endif

@@ -202,7 +202,6 @@ extern "C" void vo_destroy(vo_ctx* c)
     if (c->cloud_rows) (void)hipFree(c->cloud_rows);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_counts) (void)hipHostFree(c->h_counts);
-    if (c->host_pool) pnp_host::destroy_pool(c->host_pool);
     if (c->step_done) (void)hipEventDestroy(c->step_done);
     for (int i = 0; i < VO_NUM_STAGES; i++) { if (c->ev0[i]) (void)hipEventDestroy(c->ev0[i]); if (c->ev1[i]) (void)hipEventDestroy(c->ev1[i]); }
     if (c->stream_hi) {

@@ -106,7 +106,6 @@ struct vo_ctx {
     void* h_stage = nullptr; size_t h_stage_bytes = 0;
     vo_cloud_point* cloud = nullptr; int* cloud_rows = nullptr; // dense point cloud of one frame, built on request
     int* h_counts = nullptr; // pinned: [3][max_batch] feature / match / object-point counts of the pending step
-    void* host_pool = nullptr; // worker threads of the host-side solvers (pnp_host.cpp), created on first use
 
     // optional per-stage timing with HIP events on the context's stream
     bool timing = false;
