@@ -116,14 +116,24 @@ def _render_one(job):
     return synth.Sequence(seed=seed, width=W, height=H).frame(i)
 
 
-def render_frames(seed, W, H, count, workers):
-    """`count` consecutive stereo frames of the synthetic sequence `seed`, rendered on `workers` host processes."""
+def render_frames(seed, W, H, count, workers, cache_dir=""):
+    """`count` consecutive stereo frames of the synthetic sequence `seed`, rendered on `workers` host processes.
+    cache_dir: keep / reuse the rendered frames there (profiler passes, where the process must not fork)."""
+    cache = os.path.join(cache_dir, "frames_s%d_%dx%d_n%d.npy" % (seed, W, H, count)) if cache_dir else ""
+    if cache and os.path.exists(cache):
+        a = np.load(cache)
+        return [(a[i, 0], a[i, 1]) for i in range(count)]
     jobs = [(seed, W, H, i) for i in range(count)]
     if workers <= 1 or count <= 2:
-        return [_render_one(j) for j in jobs]
-    import multiprocessing as mp
-    with mp.get_context("fork").Pool(min(workers, count)) as pool:   # forked before this process touches a GPU
-        return pool.map(_render_one, jobs, chunksize=1)
+        out = [_render_one(j) for j in jobs]
+    else:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(workers, count)) as pool:   # forked before this process touches a GPU
+            out = pool.map(_render_one, jobs, chunksize=1)
+    if cache:
+        os.makedirs(cache_dir, exist_ok=True)
+        np.save(cache, np.stack([np.stack(f) for f in out]))
+    return out
 
 
 # ------------------------------------------------------------------ self-launch of N ranks
@@ -278,6 +288,8 @@ def parse_args(argv):
                     help="more ranks than GPUs: rank r uses GPU r mod (GPUs present) and the gather runs over gloo (plumbing rehearsal)")
     ap.add_argument("--stub-context", action="store_true", help="plumbing test without a GPU: no kernels run, the value is meaningless")
     ap.add_argument("--dump-poses", default="", help="rank 0 writes the gathered relative poses to this .npz file")
+    ap.add_argument("--frame-cache", default="", help="directory that keeps the rendered frames between runs (a run that finds "
+                    "them there renders nothing and starts no worker processes: use it under a profiler)")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--disparities", type=int, default=0)
@@ -316,7 +328,7 @@ def main(argv=None):
     nframes = args.frames if args.frames > 0 else nctx * B + 1
     nframes = max(nframes, B + 1)
     t0 = time.perf_counter()
-    frames = render_frames(seq_seed, W, H, nframes, cpu_share)
+    frames = render_frames(seq_seed, W, H, nframes, cpu_share, args.frame_cache)
     log("[rank %d] rendered %d synthetic %dx%d stereo frames in %.1f s on %d host processes" % (rank, nframes, W, H, time.perf_counter() - t0, cpu_share))
 
     import torch
