@@ -42,8 +42,8 @@ typedef enum {
     VO_ERR_NO_DEVICE = -4,
     VO_ERR_STATE = -5,        /* stage called before the stage that produces its input */
     VO_ERR_CAPACITY = -6,     /* more features than max_features; results were truncated */
-    VO_ERR_NOT_ENOUGH_POINTS = -7, /* a frame has fewer than 5 3D-2D correspondences (OpenCV throws below 4; the 4-point
-                                    * minimal solver is not provided).  In a batch the other frames are complete: see vo_step */
+    VO_ERR_NOT_ENOUGH_POINTS = -7, /* a frame has fewer than 4 3D-2D correspondences (where OpenCV throws).  In a batch the
+                                    * other frames are complete: see vo_step */
     VO_ERR_UNSUPPORTED = -8
 } vo_status;
 
@@ -241,12 +241,16 @@ const char* vo_stage_name(int stage);
 
 /* Host-side solvers of estimateMotion, callable without a GPU (used by vo_estimate_motion internally).
  * vo_host_epnp: solvePnP(SOLVEPNP_EPNP) on n >= 4 float correspondences; K row-major 3x3.
- * vo_host_pnp_iterative: solvePnP(SOLVEPNP_ITERATIVE) without a guess on f64 correspondences; returns 1,
- *   or -2 planar object (unsupported), -3 fewer than 6 points, -4 degenerate.
+ * vo_host_pnp_iterative: solvePnP(SOLVEPNP_ITERATIVE) without a guess on f64 correspondences (a planar object starts from
+ *   the plane's homography, any other from the 12-parameter DLT, then Levenberg-Marquardt); returns 1,
+ *   or -3 fewer than 6 points on a non-planar object, -4 degenerate.
+ * vo_host_p3p: solvePnP(SOLVEPNP_P3P) on exactly 4 float correspondences, which is what solvePnPRansac runs when it is
+ *   handed 4 points: returns 1, or 0 when there is no real solution.
  * vo_host_rng_subsets: the first nsubsets 5-index subsets cv::RNG((uint64)-1) yields for `count` points.
  * vo_host_rodrigues: rotation vector -> 3x3 matrix. */
 int vo_host_epnp(const vo_point3f* obj, const vo_point2f* img, int n, const double K[9], double rvec[3], double tvec[3]);
 int vo_host_pnp_iterative(const double* obj, const double* img, int n, const double K[9], double rvec[3], double tvec[3]);
+int vo_host_p3p(const vo_point3f* obj /* 4 */, const vo_point2f* img /* 4 */, const double K[9], double rvec[3], double tvec[3]);
 int vo_host_rng_subsets(int count, int nsubsets, int* idx_out /* nsubsets*5 */);
 int vo_host_rodrigues(const double rvec[3], double R[9]);
 

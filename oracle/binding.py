@@ -45,7 +45,7 @@ class StepInfo(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libvo_oracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("fast.cpp", "sgbm.cpp", "lk.cpp", "pnp.cpp", "pipeline.cpp", "vo_oracle.h", "linalg.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("fast.cpp", "sgbm.cpp", "lk.cpp", "pnp.cpp", "pnp_minimal.cpp", "pipeline.cpp", "vo_oracle.h", "linalg.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
@@ -212,6 +212,16 @@ def epnp(obj, img, K):
     t = np.zeros(3)
     lib().orc_epnp(_p(obj, Point3f), _p(img, Point2f), obj.shape[0], _p(K, C.c_double), _p(r, C.c_double), _p(t, C.c_double))
     return r, t
+
+
+def p3p(obj, img, K):
+    obj = np.ascontiguousarray(obj, dtype=np.float32)
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    K = _K(K)
+    r = np.zeros(3)
+    t = np.zeros(3)
+    ok = lib().orc_p3p(_p(obj, Point3f), _p(img, Point2f), _p(K, C.c_double), _p(r, C.c_double), _p(t, C.c_double))
+    return ok, r, t
 
 
 def pnp_iterative(obj, img, K):

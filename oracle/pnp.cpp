@@ -444,9 +444,12 @@ extern "C" int orc_pnp_iterative(const double* obj, const double* img, int n, co
     double W[3], U3[9], V3[9];
     orc::svd(MM, 3, 3, W, U3, V3);
     double param[6];
-    if (W[2] / W[1] < 1e-3) return -2; /* planar object: the homography start is not restated */
-    if (n < 6) return -3;              /* "DLT algorithm needs at least 6 points" */
-    {
+    if (W[2] / W[1] < 1e-3) { /* planar object: start from the plane's homography (pnp_minimal.cpp) */
+        double Vt[9];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Vt[r * 3 + c] = V3[c * 3 + r];
+        orc_planar_start(obj, mn.data(), n, Vt, Mc, param);
+    } else {
+        if (n < 6) return -3;          /* "DLT algorithm needs at least 6 points" */
         std::vector<double> L((size_t)2 * n * 12);
         for (int i = 0; i < n; i++) {
             double* l = &L[(size_t)i * 24];
@@ -562,9 +565,9 @@ extern "C" int orc_solve_pnp_ransac(const orc_point3f* obj, const orc_point2f* i
     if (info) *info = li;
     if (n < 4) return 0; /* OpenCV asserts npoints >= 4 */
     const int model_points = 5;
-    if (n == 4) return 0; /* P3P kernel for exactly 4 points is not restated */
-    if (n == model_points) {
-        int ok = orc_epnp(obj, img, n, K, rvec, tvec);
+    if (n == 4 || n == model_points) { /* no sampling: one minimal solve on all points (P3P on four, EPnP on five) */
+        int ok = n == 4 ? orc_p3p(obj, img, K, rvec, tvec) : orc_epnp(obj, img, n, K, rvec, tvec);
+        if (!ok) { for (int i = 0; i < 3; i++) rvec[i] = tvec[i] = 0; }
         if (inlier_mask) memset(inlier_mask, 1, n);
         li.ok = ok; li.best_inliers = n; if (info) *info = li;
         return ok;

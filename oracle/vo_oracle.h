@@ -121,6 +121,10 @@ int orc_solve_pnp_ransac(const orc_point3f* obj, const orc_point2f* img, int n, 
                          const orc_params* p, double rvec[3], double tvec[3],
                          uint8_t* inlier_mask /* nullable, n */, orc_pnp_info* info);
 /* pieces, for kernel-level tests */
+/* exactly four correspondences (solvePnP(SOLVEPNP_P3P)); 1 = solved, 0 = no real solution */
+int orc_p3p(const orc_point3f* obj, const orc_point2f* img, const double* K, double rvec[3], double tvec[3]);
+/* pose start of the iterative solver for a planar object */
+int orc_planar_start(const double* obj, const double* mn, int n, const double* Vt, const double* Mc, double param[6]);
 int orc_epnp(const orc_point3f* obj, const orc_point2f* img, int n, const double* K, double rvec[3], double tvec[3]);
 int orc_pnp_iterative(const double* obj /*n*3*/, const double* img /*n*2*/, int n, const double* K,
                       double rvec[3], double tvec[3]);

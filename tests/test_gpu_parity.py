@@ -323,7 +323,7 @@ def test_edge_cases(small_seq):
     ctx.compute_disparity()
     ctx.triangulate()
     assert len(ctx.object_points()[0]) == 0
-    # fewer than 5 correspondences: the error of OpenCV's npoints assertion, reported as a status
+    # fewer than 4 correspondences: the error of OpenCV's npoints assertion, reported as a status
     with pytest.raises(abi.VoError) as e:
         ctx.estimate_motion()
     assert e.value.code == -7

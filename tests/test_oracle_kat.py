@@ -265,9 +265,13 @@ def test_iterative_pose_and_error_codes():
     assert rc == 1 and np.allclose(rv, r, atol=5e-4) and np.allclose(tv, t, atol=1e-2)
     rc, _, _ = ob.pnp_iterative(obj[:5].astype(np.float64), img[:5].astype(np.float64), K)
     assert rc == -3
-    flat = obj.copy(); flat[:, 1] = 1.65
-    rc, _, _ = ob.pnp_iterative(flat.astype(np.float64), img.astype(np.float64), K)
-    assert rc == -2
+    # a planar object (all points on the ground plane) starts from the plane's homography instead of being refused
+    flat = obj.astype(np.float64).copy(); flat[:, 1] = 1.65
+    R, _ = ob.rodrigues(r)
+    cam = flat @ R.T + t
+    fimg = np.stack([cam[:, 0] / cam[:, 2] * K[0, 0] + K[0, 2], cam[:, 1] / cam[:, 2] * K[1, 1] + K[1, 2]], axis=1)
+    rc, rv, tv = ob.pnp_iterative(flat, fimg, K)
+    assert rc == 1 and np.allclose(rv, r, atol=1e-7) and np.allclose(tv, t, atol=1e-6)
 
 
 def test_pnp_errors_definition():

@@ -25,7 +25,7 @@ EXPORTS = (
     "vo_match_klt", "vo_get_matches", "vo_get_klt_legs", "vo_set_matches", "vo_triangulate", "vo_get_object_points",
     "vo_pnp_score", "vo_estimate_motion", "vo_integrate_pose", "vo_step", "vo_step_submit", "vo_step_finish", "vo_read_tap", "vo_pyramid_info",
     "vo_set_timing", "vo_get_timing", "vo_stage_name",
-    "vo_host_epnp", "vo_host_pnp_iterative", "vo_host_rng_subsets", "vo_host_rodrigues",
+    "vo_host_epnp", "vo_host_pnp_iterative", "vo_host_p3p", "vo_host_rng_subsets", "vo_host_rodrigues",
 )
 NUM_STAGES = 16
 # vo_cloud_point

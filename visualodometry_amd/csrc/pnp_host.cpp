@@ -1,6 +1,7 @@
 // Host-side minimal solvers and RANSAC bookkeeping (see pnp_host.h).  f64, compiled without FP contraction.
 #include "pnp_host.h"
 #include "small_linalg.h"
+#include <math.h>
 #include <string.h>
 #include <thread>
 #include <atomic>
@@ -382,7 +383,222 @@ inline Projection project(const double R[9], const double t[3], const double K[9
     return p;
 }
 
+// Plane-to-image homography by the normalised direct linear transform: both point sets are centred and scaled by their
+// mean absolute deviation per axis, the 9-vector is the eigenvector of the smallest eigenvalue of L^T L, and the result
+// is mapped back and scaled to h[8] = 1.  (The original follows this with a few Levenberg-Marquardt steps on the
+// homography; here the 6-parameter pose refinement that follows makes that polish immaterial.)
+bool homography_dlt(const double* M /* n x 2 */, const double* m /* n x 2 */, int n, double h[9], sla::SvdWorkspace& ws)
+{
+    double cM[2] = {0, 0}, cm[2] = {0, 0}, sM[2] = {0, 0}, sm[2] = {0, 0};
+    for (int i = 0; i < n; i++) { cM[0] += M[2 * i]; cM[1] += M[2 * i + 1]; cm[0] += m[2 * i]; cm[1] += m[2 * i + 1]; }
+    for (int k = 0; k < 2; k++) { cM[k] /= n; cm[k] /= n; }
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 2; k++) { sM[k] += std::abs(M[2 * i + k] - cM[k]); sm[k] += std::abs(m[2 * i + k] - cm[k]); }
+    for (int k = 0; k < 2; k++) if (std::abs(sM[k]) < DBL_EPSILON || std::abs(sm[k]) < DBL_EPSILON) return false;
+    for (int k = 0; k < 2; k++) { sM[k] = n / sM[k]; sm[k] = n / sm[k]; }
+    double LtL[81];
+    for (int k = 0; k < 81; k++) LtL[k] = 0;
+    for (int i = 0; i < n; i++) {
+        const double X = (M[2 * i] - cM[0]) * sM[0], Y = (M[2 * i + 1] - cM[1]) * sM[1];
+        const double x = (m[2 * i] - cm[0]) * sm[0], y = (m[2 * i + 1] - cm[1]) * sm[1];
+        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x}, Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+        for (int r = 0; r < 9; r++) for (int c = r; c < 9; c++) LtL[r * 9 + c] += Lx[r] * Lx[c] + Ly[r] * Ly[c];
+    }
+    for (int r = 0; r < 9; r++) for (int c = 0; c < r; c++) LtL[r * 9 + c] = LtL[c * 9 + r];
+    double W[9], U[81], V[81], H0[9];
+    sla::svd(LtL, 9, 9, W, U, V, ws);
+    for (int k = 0; k < 9; k++) H0[k] = V[k * 9 + 8];
+    // H = inv(T_image) * H0 * T_object with T(p) = (p - c) * s
+    const double invT[9] = {1. / sm[0], 0, cm[0], 0, 1. / sm[1], cm[1], 0, 0, 1};
+    const double T2[9] = {sM[0], 0, -cM[0] * sM[0], 0, sM[1], -cM[1] * sM[1], 0, 0, 1};
+    double tmp[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) tmp[r * 3 + c] = invT[r * 3] * H0[c] + invT[r * 3 + 1] * H0[3 + c] + invT[r * 3 + 2] * H0[6 + c];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) h[r * 3 + c] = tmp[r * 3] * T2[c] + tmp[r * 3 + 1] * T2[3 + c] + tmp[r * 3 + 2] * T2[6 + c];
+    if (std::abs(h[8]) < DBL_MIN) return false;
+    const double s = 1. / h[8];
+    for (int k = 0; k < 9; k++) h[k] *= s;
+    return true;
+}
+
 } // namespace
+
+// ------------------------------------------------------------------ P3P (Gao, Hou, Tang, Chang 2003) on exactly four points
+namespace {
+
+int real_roots_cubic(double a, double b, double c, double d, double x[3])
+{
+    if (a == 0) {
+        if (b == 0) { if (c == 0) return 0; x[0] = -d / c; return 1; }
+        const double disc = c * c - 4 * b * d;
+        if (disc < 0) return 0;
+        const double inv2b = 1. / (2 * b);
+        if (disc == 0) { x[0] = x[1] = -c * inv2b; return 1; }
+        const double sq = std::sqrt(disc);
+        x[0] = (-c + sq) * inv2b; x[1] = (-c - sq) * inv2b;
+        return 2;
+    }
+    const double ia = 1. / a, ba = ia * b, ba2 = ba * ba, ca = ia * c, da = ia * d;
+    const double Q = (3 * ca - ba2) / 9, R = (9 * ba * ca - 27 * da - 2 * ba * ba2) / 54;
+    const double Q3 = Q * Q * Q, D = Q3 + R * R, shift = (1. / 3.) * ba;
+    if (Q == 0) {
+        if (R == 0) { x[0] = x[1] = x[2] = -shift; return 3; }
+        x[0] = std::pow(2 * R, 1 / 3.0) - shift;
+        return 1;
+    }
+    if (D <= 0) { // three real roots, trigonometric form
+        const double theta = std::acos(R / std::sqrt(-Q3)), sq = std::sqrt(-Q);
+        x[0] = 2 * sq * std::cos(theta / 3.0) - shift;
+        x[1] = 2 * sq * std::cos((theta + 2 * M_PI) / 3.0) - shift;
+        x[2] = 2 * sq * std::cos((theta + 4 * M_PI) / 3.0) - shift;
+        return 3;
+    }
+    const double AD = std::pow(std::abs(R) + std::sqrt(D), 1.0 / 3.0) * (R > 0 ? 1 : (R < 0 ? -1 : 0));
+    const double BD = AD == 0 ? 0 : -Q / AD;
+    x[0] = AD + BD - shift;
+    return 1;
+}
+
+// real roots of a x^4 + b x^3 + c x^2 + d x + e by Ferrari's resolvent cubic
+int real_roots_quartic(double a, double b, double c, double d, double e, double x[4])
+{
+    if (a == 0) return real_roots_cubic(b, c, d, e, x);
+    const double ia = 1. / a;
+    b *= ia; c *= ia; d *= ia; e *= ia;
+    const double b2 = b * b, bc = b * c, b3 = b2 * b;
+    double r[3];
+    if (real_roots_cubic(1, -c, d * b - 4 * e, 4 * c * e - d * d - b2 * e, r) == 0) return 0;
+    const double R2 = 0.25 * b2 - c + r[0];
+    if (R2 < 0) return 0;
+    const double R = std::sqrt(R2);
+    double D2, E2;
+    if (R < 10E-12) {
+        const double t = r[0] * r[0] - 4 * e;
+        if (t < 0) D2 = E2 = -1;
+        else { const double st = std::sqrt(t); D2 = 0.75 * b2 - 2 * c + 2 * st; E2 = D2 - 4 * st; }
+    } else {
+        const double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * (1. / R) * (4 * bc - 8 * d - b3);
+        D2 = u + v; E2 = u - v;
+    }
+    const double b_4 = 0.25 * b, R_2 = 0.5 * R;
+    int nr = 0;
+    if (D2 >= 0) { const double Dv = std::sqrt(D2); x[0] = R_2 + 0.5 * Dv - b_4; x[1] = x[0] - Dv; nr = 2; }
+    if (E2 >= 0) { const double Ev = std::sqrt(E2); x[nr] = -R_2 + 0.5 * Ev - b_4; x[nr + 1] = x[nr] - Ev; nr += 2; }
+    return nr;
+}
+
+// |PA|, |PB|, |PC| from the side lengths dist = (|BC|, |AC|, |AB|) and the cosines of (BPC, APC, APB); up to 4 solutions
+int p3p_lengths(double lengths[4][3], const double dist[3], const double cosv[3])
+{
+    const double p = cosv[0] * 2, q = cosv[1] * 2, r = cosv[2] * 2;
+    const double inv_d22 = 1. / (dist[2] * dist[2]);
+    const double a = inv_d22 * (dist[0] * dist[0]), b = inv_d22 * (dist[1] * dist[1]);
+    const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r, pr = p * r, pqr = q * pr;
+    if (p2 + q2 + r2 - pqr - 1 == 0) return 0; // the projection centre is coplanar with the three points
+    const double ab = a * b, a_2 = 2 * a, a_4 = 4 * a;
+    const double A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
+    if (A == 0) return 0;
+    const double B = q * (-2 * (ab + a2 + 1 - b) + r2 * ab + a_4) + pr * (b - b2 + ab);
+    const double C = q2 + b2 * (r2 + p2 - 2) - b * (p2 + pqr) - ab * (r2 + pqr) + (a2 - a_2) * (2 + q2) + 2;
+    const double D = pr * (ab - b2 + b) + q * ((p2 - 2) * b + 2 * (ab - a2) + a_4 - 2);
+    const double E = 1 + 2 * (b - a - ab) + b2 - b * p2 + a2;
+    const double temp = p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr;
+    const double b0 = b * temp * temp;
+    if (b0 == 0) return 0;
+    double roots[4];
+    const int n = real_roots_quartic(A, B, C, D, E, roots);
+    int ns = 0;
+    const double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q, inv_b0 = 1. / b0;
+    for (int i = 0; i < n; i++) {
+        const double x = roots[i];
+        if (x <= 0) continue;
+        const double x2 = x * x;
+        const double b1 = ((1 - a - b) * x2 + (q * a - q) * x + 1 - a + b) *
+            (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
+              (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * x2 +
+             (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+              pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
+             2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+             p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
+        if (b1 <= 0) continue;
+        const double y = inv_b0 * b1, v = x2 + y * y - x * y * r;
+        if (v <= 0) continue;
+        const double Z = dist[2] / std::sqrt(v);
+        lengths[ns][0] = x * Z; lengths[ns][1] = y * Z; lengths[ns][2] = Z;
+        ns++;
+    }
+    return ns;
+}
+
+// rigid motion that takes three world points onto three camera-frame points (least squares through the SVD of the
+// cross-covariance; exact for three non-collinear points)
+bool align3(const double cam[3][3], const double wld[3][3], double R[9], double t[3], sla::SvdWorkspace& ws)
+{
+    double cc[3] = {0, 0, 0}, cw[3] = {0, 0, 0};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { cc[j] += cam[i][j] / 3; cw[j] += wld[i][j] / 3; }
+    double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; i++) for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) S[r * 3 + c] += (cam[i][r] - cc[r]) * (wld[i][c] - cw[c]);
+    double w[3], U[9], V[9];
+    sla::svd(S, 3, 3, w, U, V, ws);
+    if (!(w[1] > 1e-12 * w[0])) return false; // collinear points
+    sla::uvt3(U, V, R);
+    if (sla::det3(R) < 0) { // reflection: flip the direction of least variance
+        for (int r = 0; r < 3; r++) U[r * 3 + 2] = -U[r * 3 + 2];
+        sla::uvt3(U, V, R);
+    }
+    for (int r = 0; r < 3; r++) t[r] = cc[r] - (R[r * 3] * cw[0] + R[r * 3 + 1] * cw[1] + R[r * 3 + 2] * cw[2]);
+    return true;
+}
+
+} // namespace
+
+// solvePnP(SOLVEPNP_P3P) as cv::solvePnPRansac uses it when it is handed exactly four correspondences: the first three
+// points give up to four poses, the one with the smallest reprojection error over the four points is returned.
+int p3p4(const vo_point3f* obj, const vo_point2f* img, const double K[9], double rvec[3], double tvec[3])
+{
+    sla::SvdWorkspace ws;
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    double mu[4], mv[4], mk[3], pix[4][2];
+    for (int i = 0; i < 4; i++) {
+        // the image points pass through an undistort-and-reproject step (identity here) that stores them as float
+        pix[i][0] = (double)(float)((((double)img[i].x - cx) / fx) * fx + cx);
+        pix[i][1] = (double)(float)((((double)img[i].y - cy) / fy) * fy + cy);
+        mu[i] = (pix[i][0] - cx) / fx; mv[i] = (pix[i][1] - cy) / fy;
+    }
+    for (int i = 0; i < 3; i++) { mk[i] = 1. / std::sqrt(mu[i] * mu[i] + mv[i] * mv[i] + 1); mu[i] *= mk[i]; mv[i] *= mk[i]; }
+    double X[4][3];
+    for (int i = 0; i < 4; i++) { X[i][0] = obj[i].x; X[i][1] = obj[i].y; X[i][2] = obj[i].z; }
+    auto d3 = [&](int a, int b) { return std::sqrt((X[a][0] - X[b][0]) * (X[a][0] - X[b][0]) + (X[a][1] - X[b][1]) * (X[a][1] - X[b][1]) + (X[a][2] - X[b][2]) * (X[a][2] - X[b][2])); };
+    const double dist[3] = {d3(1, 2), d3(0, 2), d3(0, 1)};
+    const double cosv[3] = {mu[1] * mu[2] + mv[1] * mv[2] + mk[1] * mk[2], mu[0] * mu[2] + mv[0] * mv[2] + mk[0] * mk[2],
+                            mu[0] * mu[1] + mv[0] * mv[1] + mk[0] * mk[1]};
+    double lengths[4][3];
+    const int ns = p3p_lengths(lengths, dist, cosv);
+    double best = DBL_MAX, bestR[9], bestT[3];
+    bool found = false;
+    for (int s = 0; s < ns; s++) {
+        double cam[3][3], wld[3][3], R[9], t[3];
+        for (int i = 0; i < 3; i++) {
+            cam[i][0] = lengths[s][i] * mu[i]; cam[i][1] = lengths[s][i] * mv[i]; cam[i][2] = lengths[s][i] * mk[i];
+            for (int j = 0; j < 3; j++) wld[i][j] = X[i][j];
+        }
+        if (!align3(cam, wld, R, t, ws)) continue;
+        double err = 0;
+        for (int i = 0; i < 4; i++) {
+            const double xc = R[0] * X[i][0] + R[1] * X[i][1] + R[2] * X[i][2] + t[0];
+            const double yc = R[3] * X[i][0] + R[4] * X[i][1] + R[5] * X[i][2] + t[1];
+            const double zc = R[6] * X[i][0] + R[7] * X[i][1] + R[8] * X[i][2] + t[2];
+            const double du = fx * xc / zc + cx - pix[i][0], dv = fy * yc / zc + cy - pix[i][1];
+            err += du * du + dv * dv;
+        }
+        if (!(err < best)) continue; // the first of equally good solutions stays, as a stable sort would keep it
+        best = err; found = true;
+        memcpy(bestR, R, sizeof(R)); memcpy(bestT, t, sizeof(t));
+    }
+    if (!found) return 0;
+    rodrigues_from_matrix(bestR, rvec);
+    for (int i = 0; i < 3; i++) tvec[i] = bestT[i];
+    return 1;
+}
 
 int iterative(const double* obj, const double* img, int n, const double K[9], double rvec[3], double tvec[3])
 {
@@ -404,10 +620,45 @@ int iterative(const double* obj, const double* img, int n, const double K[9], do
     }
     double W[3], U3[9], V3[9];
     sla::svd(MM, 3, 3, W, U3, V3, ws);
-    if (W[2] / W[1] < 1e-3) return -2;
-    if (n < 6) return -3;
     double param[6];
-    {
+    if (W[2] / W[1] < 1e-3) {
+        // All object points lie in one plane: the projection is a homography of the plane's own 2-D coordinates.
+        // Rotate the object into the frame of its principal axes (third axis = plane normal), estimate the homography
+        // to the normalised image points, and read [r1 r2 t] off its columns.
+        double Rtf[9], Ttf[3]; // rows of Rtf = principal axes
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rtf[r * 3 + c] = V3[c * 3 + r];
+        if (Rtf[2] * Rtf[2] + Rtf[5] * Rtf[5] < 1e-10) { for (int k = 0; k < 9; k++) Rtf[k] = (k % 4 == 0) ? 1 : 0; }
+        if (sla::det3(Rtf) < 0) for (int k = 0; k < 9; k++) Rtf[k] = -Rtf[k];
+        for (int r = 0; r < 3; r++) Ttf[r] = -(Rtf[r * 3] * Mc[0] + Rtf[r * 3 + 1] * Mc[1] + Rtf[r * 3 + 2] * Mc[2]);
+        std::vector<double> Mxy((size_t)2 * n);
+        for (int i = 0; i < n; i++) {
+            const double* M = &obj[3 * i];
+            Mxy[2 * i] = Rtf[0] * M[0] + Rtf[1] * M[1] + Rtf[2] * M[2] + Ttf[0];
+            Mxy[2 * i + 1] = Rtf[3] * M[0] + Rtf[4] * M[1] + Rtf[5] * M[2] + Ttf[1];
+        }
+        double h[9];
+        bool ok = n >= 4 && homography_dlt(Mxy.data(), mn.data(), n, h, ws);
+        for (int k = 0; k < 9 && ok; k++) ok = std::isfinite(h[k]);
+        double R[9], t[3] = {0, 0, 0};
+        if (ok) {
+            const double n1 = std::sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]), n2 = std::sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+            const double s1 = 1. / std::max(n1, DBL_EPSILON), s2 = 1. / std::max(n2, DBL_EPSILON), s3 = 2. / std::max(n1 + n2, DBL_EPSILON);
+            double c1[3] = {h[0] * s1, h[3] * s1, h[6] * s1}, c2[3] = {h[1] * s2, h[4] * s2, h[7] * s2};
+            double tt[3] = {h[2] * s3, h[5] * s3, h[8] * s3};
+            double c3[3] = {c1[1] * c2[2] - c1[2] * c2[1], c1[2] * c2[0] - c1[0] * c2[2], c1[0] * c2[1] - c1[1] * c2[0]};
+            double Hm[9] = {c1[0], c2[0], c3[0], c1[1], c2[1], c3[1], c1[2], c2[2], c3[2]}, rv[3], Rh[9];
+            rodrigues_from_matrix(Hm, rv);          // nearest rotation to [c1 c2 c3] ...
+            rodrigues_to_matrix(rv, Rh, nullptr);   // ... as a proper rotation matrix
+            for (int r = 0; r < 3; r++) t[r] = Rh[r * 3] * Ttf[0] + Rh[r * 3 + 1] * Ttf[1] + Rh[r * 3 + 2] * Ttf[2] + tt[r];
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++)
+                R[r * 3 + c] = Rh[r * 3] * Rtf[c] + Rh[r * 3 + 1] * Rtf[3 + c] + Rh[r * 3 + 2] * Rtf[6 + c];
+        } else {
+            for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1 : 0;
+        }
+        rodrigues_from_matrix(R, param);
+        for (int k = 0; k < 3; k++) param[3 + k] = t[k];
+    } else {
+        if (n < 6) return -3;
         std::vector<double> L((size_t)2 * n * 12);
         for (int i = 0; i < n; i++) {
             double* l = &L[(size_t)i * 24];
@@ -641,8 +892,8 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
         FrameRansac& f = fr[b];
         f.k = k; f.obj = objs[b].data(); f.img = imgs[b].data();
         f.niters = std::max(c->p.ransac_iters, 1);
-        if (k < 5) { f.failed = true; status = VO_ERR_NOT_ENOUGH_POINTS; } // 4-point P3P kernel is not provided
-        else if (k == model_points) f.direct = true;
+        if (k < 4) { f.failed = true; status = VO_ERR_NOT_ENOUGH_POINTS; } // the original asserts at least 4 points
+        else if (k == 4 || k == model_points) f.direct = true;          // no sampling: one minimal solve on all points
         else f.active = true;
     }
 
@@ -721,8 +972,10 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
         o.n_features = c->h_nfeat[b]; o.n_matched = c->h_nmatch[b]; o.n_object_points = f.k;
         double rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0};
         if (f.direct) {
-            epnp(f.obj, f.img, f.k, K, rvec, tvec);
-            o.ok = 1; o.best_inliers = f.k;
+            if (f.k == 4) o.ok = p3p4(f.obj, f.img, K, rvec, tvec);
+            else { epnp(f.obj, f.img, f.k, K, rvec, tvec); o.ok = 1; }
+            if (!o.ok) rvec[0] = rvec[1] = rvec[2] = tvec[0] = tvec[1] = tvec[2] = 0;
+            o.best_inliers = o.ok ? f.k : 0;
         } else if (!f.failed && f.max_good > 0) {
             o.iters_run = f.iter; o.best_inliers = f.max_good;
             std::vector<double> po, pi;
@@ -757,7 +1010,7 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
         c->stage_ms[VO_ST_PNP_HOST] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host0).count();
         c->stage_calls[VO_ST_PNP_HOST]++;
     }
-    if (status != VO_OK) return vo_fail(c, status, "a frame of the batch has fewer than 5 3D-2D correspondences");
+    if (status != VO_OK) return vo_fail(c, status, "a frame of the batch has fewer than 4 3D-2D correspondences");
     return VO_OK;
 }
 

@@ -26,8 +26,13 @@ bool inv4x4(const double* A, double* Ainv);
 // solvePnP(SOLVEPNP_EPNP) on float correspondences; K row-major 3x3
 void epnp(const vo_point3f* obj, const vo_point2f* img, int n, const double K[9], double rvec[3], double tvec[3]);
 // solvePnP(SOLVEPNP_ITERATIVE) without an extrinsic guess on f64 correspondences.
-// returns 1, or -2 planar object (not supported), -3 fewer than 6 points, -4 degenerate
+// (planar objects start from the plane's homography, others from the 12-parameter DLT);
+// returns 1, or -3 fewer than 6 points on a non-planar object, -4 degenerate
 int iterative(const double* obj, const double* img, int n, const double K[9], double rvec[3], double tvec[3]);
+
+// solvePnP(SOLVEPNP_P3P) on exactly four float correspondences (what solvePnPRansac runs when handed four points);
+// returns 1, or 0 when the three-point problem has no real solution
+int p3p4(const vo_point3f* obj, const vo_point2f* img, const double K[9], double rvec[3], double tvec[3]);
 
 // RANSAC + refine for every frame of the current batch; hypotheses are scored by the GPU kernel.
 int estimate_motion_batch(vo_ctx* c, double* Rt_out, vo_frame_info* info);

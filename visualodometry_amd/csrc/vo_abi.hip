@@ -723,6 +723,12 @@ extern "C" int vo_host_pnp_iterative(const double* obj, const double* img, int n
     return pnp_host::iterative(obj, img, n, K, rvec, tvec);
 }
 
+extern "C" int vo_host_p3p(const vo_point3f* obj, const vo_point2f* img, const double K[9], double rvec[3], double tvec[3])
+{
+    if (!obj || !img || !K || !rvec || !tvec) return VO_ERR_BAD_ARG;
+    return pnp_host::p3p4(obj, img, K, rvec, tvec);
+}
+
 extern "C" int vo_host_rng_subsets(int count, int nsubsets, int* idx_out)
 {
     if (count < 5 || nsubsets < 0 || !idx_out) return VO_ERR_BAD_ARG;
