@@ -76,6 +76,14 @@ def default_params(width, height, **kw):
     return p
 
 
+VAR_PATH_START_C, VAR_DISP12_ZERO, VAR_RAW_BORDER_PIXEL, VAR_LK_FLOAT_ACC, VAR_LK_NO_ERR_STATUS = 1, 2, 4, 8, 16
+
+
+def set_variant(flags):
+    """Sensitivity switches (vo_oracle.h): replaces assumptions about OpenCV's internals by their alternatives.  0 restores."""
+    lib().orc_set_variant(C.c_uint(int(flags)))
+
+
 def set_threads(n):
     lib().orc_set_threads(int(n))
 

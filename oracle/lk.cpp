@@ -168,6 +168,8 @@ void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, or
 
     std::vector<int16_t> Iw((size_t)win * win), dIw((size_t)win * win * 2);
     int64_t iA11 = 0, iA12 = 0, iA22 = 0;
+    const bool facc = (orc_get_variant() & ORC_VAR_LK_FLOAT_ACC) != 0;
+    float fA11 = 0, fA12 = 0, fA22 = 0;
     const int stepI = I.stride, dstep = I.stride * 2;
     for (int y = 0; y < win; y++) {
         const uint8_t* src = I.at(y + ipy, ipx);
@@ -182,9 +184,11 @@ void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, or
             iA11 += (int)(ixval * ixval);
             iA12 += (int)(ixval * iyval);
             iA22 += (int)(iyval * iyval);
+            fA11 += (float)(ixval * ixval); fA12 += (float)(ixval * iyval); fA22 += (float)(iyval * iyval);
         }
     }
     float A11 = iA11 * FLT_SCALE, A12 = iA12 * FLT_SCALE, A22 = iA22 * FLT_SCALE;
+    if (facc) { A11 = fA11 * FLT_SCALE; A12 = fA12 * FLT_SCALE; A22 = fA22 * FLT_SCALE; }
     float Dt = A11 * A22 - A12 * A12;
     float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
     if (minEig < min_eig_thr || Dt < FLT_EPSILON) {
@@ -211,6 +215,7 @@ void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, or
         iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
         iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         int64_t ib1 = 0, ib2 = 0;
+        float fb1 = 0, fb2 = 0;
         for (int y = 0; y < win; y++) {
             const uint8_t* Jp = J.at(y + iny, inx);
             for (int x = 0; x < win; x++) {
@@ -218,9 +223,11 @@ void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, or
                            Iw[(size_t)y * win + x];
                 ib1 += (int)(diff * dIw[((size_t)y * win + x) * 2]);
                 ib2 += (int)(diff * dIw[((size_t)y * win + x) * 2 + 1]);
+                fb1 += (float)(diff * dIw[((size_t)y * win + x) * 2]); fb2 += (float)(diff * dIw[((size_t)y * win + x) * 2 + 1]);
             }
         }
         float b1 = ib1 * FLT_SCALE, b2 = ib2 * FLT_SCALE;
+        if (facc) { b1 = fb1 * FLT_SCALE; b2 = fb2 * FLT_SCALE; }
         orc_point2f delta = {(float)((A12 * b2 - A22 * b1) * Dt), (float)((A12 * b1 - A11 * b2) * Dt)};
         nextPt.x += delta.x; nextPt.y += delta.y;
         next_pt_io->x = nextPt.x + half; next_pt_io->y = nextPt.y + half;
@@ -233,7 +240,7 @@ void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, or
     }
     g_lk_hist[iters_run < 51 ? iters_run : 51]++;
     /* error block of the original: runs because the caller passes `err`; its bounds test can clear status */
-    if (*status && level == 0) {
+    if (*status && level == 0 && !(orc_get_variant() & ORC_VAR_LK_NO_ERR_STATUS)) {
         orc_point2f np = {next_pt_io->x - half, next_pt_io->y - half};
         int inx = cv_floor(np.x), iny = cv_floor(np.y);
         if (inx < -win || inx >= J.w || iny < -win || iny >= J.h) { *status = 0; return; }

@@ -16,6 +16,7 @@
 namespace {
 
 int g_threads = 1;
+unsigned g_variant = 0; /* sensitivity switches, see vo_oracle.h */
 
 struct Sgbm {
     int W, H, minD, maxD, D, minX1, maxX1, width1, SW2, SH2, P1, P2, ftzero, disp12MaxDiff, uniq, lanes;
@@ -53,6 +54,7 @@ void pixel_cost_row(const Sgbm& s, int y, std::vector<int16_t>& pix,
         p1[W + x] = r1[x];
         p2[W + x] = r2[x];
     }
+    if (g_variant & ORC_VAR_RAW_BORDER_PIXEL) { p1[W] = r1[0]; p1[2 * W - 1] = r1[W - 1]; p2[W] = r2[0]; p2[2 * W - 1] = r2[W - 1]; }
     pix.assign((size_t)s.width1 * s.D, 0);
     v0b.resize(W); v1b.resize(W);
     for (int c = 0; c < 2; c++) {
@@ -145,7 +147,8 @@ void run_stripe(const Sgbm& s, int n, int stripe_sz, int overlap, int16_t* disp,
     std::vector<uint8_t> t1, t2, t3, t4;
     /* path state: zero cost, zero minimum before the first pixel of every path (path_init) */
     std::vector<int16_t> top((size_t)w1 * D, 0), left((size_t)(w1 + 1) * D, 0), right(D), tmp(D), Ssum((size_t)w1 * D);
-    std::vector<int> topMin(w1, 0);
+    const int startMin = (g_variant & ORC_VAR_PATH_START_C) ? -s.P2 : 0; /* path_init: the minimum "before" a path's first pixel */
+    std::vector<int> topMin(w1, startMin);
     std::vector<int16_t> disp2(W), disp2cost(W), row(W);
 
     auto hs_of = [&](int k) -> std::vector<int16_t>& { return ring[std::min(k, H - 1) % ring_n]; };
@@ -171,7 +174,7 @@ void run_stripe(const Sgbm& s, int n, int stripe_sz, int overlap, int16_t* disp,
         for (int x = 0; x < W; x++) { row[x] = (int16_t)INVALID; disp2[x] = (int16_t)INVALID; disp2cost[x] = SHRT_MAX; }
 
         /* ---- left->right and top->bottom paths ---- */
-        int leftMin = 0;
+        int leftMin = startMin;
         std::fill(left.begin(), left.begin() + D, (int16_t)0);
         for (int x = 0; x < w1; x++) {
             const int16_t* Cx = &C[(size_t)x * D];
@@ -180,7 +183,7 @@ void run_stripe(const Sgbm& s, int n, int stripe_sz, int overlap, int16_t* disp,
             topMin[x] = path_step(Cx, tmp.data(), topMin[x], D, s.P1, s.P2, &top[(size_t)x * D]);
         }
         /* ---- right->left path, sum, WTA, disp2, sub-pixel ---- */
-        int rightMin = 0;
+        int rightMin = startMin;
         std::fill(right.begin(), right.end(), (int16_t)0);
         for (int x = w1 - 1; x >= 0; x--) {
             const int16_t* Cx = &C[(size_t)x * D];
@@ -229,7 +232,7 @@ bool make_sgbm(const uint8_t* left, const uint8_t* right, const orc_params* p, S
     s->SW2 = s->SH2 = p->block_size > 0 ? p->block_size / 2 : 1;
     s->P1 = p->p1 > 0 ? p->p1 : 2; s->P2 = std::max(p->p2 > 0 ? p->p2 : 5, s->P1 + 1);
     s->uniq = p->uniqueness_ratio >= 0 ? p->uniqueness_ratio : 10;
-    s->disp12MaxDiff = p->disp12_max_diff > 0 ? p->disp12_max_diff : 1;
+    s->disp12MaxDiff = p->disp12_max_diff > 0 ? p->disp12_max_diff : ((g_variant & ORC_VAR_DISP12_ZERO) ? 0 : 1);
     s->ftzero = std::max(p->pre_filter_cap, 15) | 1;
     s->lanes = p->wta_simd_lanes;
     return s->width1 > 0 && s->D > 0 && s->D % 16 == 0 && s->minD == 0;
@@ -252,6 +255,8 @@ void median3x3_s16(const int16_t* src, int W, int H, int16_t* dst)
 
 } // namespace
 
+extern "C" void orc_set_variant(unsigned flags) { g_variant = flags; }
+extern "C" unsigned orc_get_variant(void) { return g_variant; }
 extern "C" void orc_set_threads(int n) { g_threads = std::max(1, n); }
 extern "C" int orc_get_threads(void) { return g_threads; }
 

@@ -121,6 +121,18 @@ int orc_solve_pnp_ransac(const orc_point3f* obj, const orc_point2f* img, int n, 
                          const orc_params* p, double rvec[3], double tvec[3],
                          uint8_t* inlier_mask /* nullable, n */, orc_pnp_info* info);
 /* pieces, for kernel-level tests */
+/* Sensitivity switches (tests/golden/make_ocvk_sensitivity.py): each bit replaces ONE assumption about OpenCV 4.5.4's
+ * internals by its plausible alternative, so that the effect of being wrong about it can be measured.  0 = the restatement. */
+enum {
+    ORC_VAR_PATH_START_C = 1,      /* first pixel of a path: L = C (instead of C - P2, zero state with zero minimum) */
+    ORC_VAR_DISP12_ZERO = 2,       /* disp12MaxDiff <= 0 stays 0 (instead of being taken as 1) */
+    ORC_VAR_RAW_BORDER_PIXEL = 4,  /* raw-intensity channel keeps the pixel in columns 0 and W-1 (instead of the table's zero entry) */
+    ORC_VAR_LK_FLOAT_ACC = 8,      /* LK sums in float, in scan order (instead of exact integer sums) */
+    ORC_VAR_LK_NO_ERR_STATUS = 16  /* LK: no re-test of the final window position after the iterations */
+};
+void orc_set_variant(unsigned flags);
+unsigned orc_get_variant(void);
+
 /* exactly four correspondences (solvePnP(SOLVEPNP_P3P)); 1 = solved, 0 = no real solution */
 int orc_p3p(const orc_point3f* obj, const orc_point2f* img, const double* K, double rvec[3], double tvec[3]);
 /* pose start of the iterative solver for a planar object */
