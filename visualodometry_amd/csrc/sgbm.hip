@@ -410,6 +410,235 @@ __global__ __launch_bounds__(vo_cost_threads(NP)) void cost_vpath_kernel(const u
     }
 }
 
+// ---------------------------------------------------------------- the same for wide disparity ranges (160 .. 256)
+// With 10 .. 16 cells per lane and column the kernel above needs ~200 registers, which leaves one 512-thread block per CU:
+// two wavefronts per SIMD, all in one barrier domain, cannot hide the per-row barrier and the memory latency.  This form
+// is written for 128 registers, so that two blocks (four wavefronts per SIMD) share a CU:
+//   - no ring: the row that leaves the vertical window is evaluated again and subtracted, so no per-thread row history
+//     exists, neither in registers nor in LDS nor in memory;
+//   - the prefiltered pixels a tile needs for one image row (64 left, D + 64 right) are staged in LDS by the whole block,
+//     one row ahead: a thread requests its two pixels at the top of a row and stores them to LDS at the bottom, so the
+//     memory latency hides behind the row's arithmetic, and every lane then reads its 2NP + 1 right pixels from LDS
+//     (one pad slot per 16 pixels keeps the lanes of a group, 2NP pixels apart, on different banks);
+//   - every evaluated cost goes straight into the running sum V (one packed multiply-add), nothing is kept per row;
+//   - the horizontal window is summed one register column (k) at a time.
+template <int NP>
+struct WideTile {
+    static constexpr int NCOL = 2, THREADS = 512;
+    static constexpr int CV_COLS = (THREADS / 16) * NCOL;  // 64
+    static constexpr int CS = 16 * NP + 4;                  // dwords per tile column of V
+    static constexpr int RPX = CV_COLS + 32 * NP;           // right pixels per tile and row: x0 - D .. x0 + 63
+    static constexpr int RSLOTS = RPX + RPX / 16;           // with the pad slots
+    static constexpr int EVAL_SLOTS = RSLOTS + CV_COLS;     // + the left pixels
+    static constexpr int ENTRIES = RPX + CV_COLS;           // pixels fetched per row evaluation
+    static constexpr size_t lds_bytes() { return (size_t)2 * CV_COLS * CS * 4 + (size_t)2 * 2 * EVAL_SLOTS * 8; }
+};
+
+template <int NP, int SWC>
+__global__ __launch_bounds__(512, 4) void cost_vpath_wide_kernel(const uint2* __restrict__ pre, int W, int H, int Wp, int width1, int D, int SW2,
+                                                                 int srows, StripeInfo si, int P1, int P2, int16_t* __restrict__ cost,
+                                                                 int16_t* __restrict__ agg)
+{
+    typedef WideTile<NP> T;
+    constexpr int NCOL = T::NCOL, CV_COLS = T::CV_COLS, CS = T::CS;
+    constexpr int NR = 2 * NP + NCOL - 1;
+    extern __shared__ int vt[];                    // [2][CV_COLS][CS] V tiles, then [2][2][EVAL_SLOTS] staged pixels (8 bytes each)
+    v2u32* stage = reinterpret_cast<v2u32*>(vt + 2 * CV_COLS * CS);
+    const int lane16 = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int stripe = blockIdx.y, b = blockIdx.z;
+    const int y0 = si.y0[stripe], rows = si.rows[stripe];
+    if (rows <= 0) return;
+    const int tile_out = CV_COLS - 2 * SW2;
+    const int xc0 = blockIdx.x * tile_out - SW2;
+    const int minX1 = W - width1;
+    const int cb = q * NCOL;
+    const int d0 = lane16 * 2 * NP;
+    const unsigned img_bytes = (unsigned)H * (unsigned)Wp * 8u;
+    const unsigned row_pitch = (unsigned)Wp * 8u;
+    // one descriptor over both prefiltered images of the frame (left, then right)
+    const __amdgpu_buffer_rsrc_t Prs = make_rsrc(pre + (size_t)b * 2 * H * Wp, 2u * img_bytes);
+
+    // ---- staging: entry n of a row's 2 * ENTRIES pixels: evaluation e = n / ENTRIES (0: leaving row, 1: entering row),
+    // then right pixels x0 - D + m (m < RPX) and left pixels x0 + m - RPX.  Pixels outside the image are never used.
+    const int x0 = minX1 + xc0; // image column of tile column 0
+    int st_slot[2]; unsigned st_off[2]; bool st_enter[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int n = (int)threadIdx.x + u * T::THREADS;
+        const int e = n / T::ENTRIES, mm = n - e * T::ENTRIES;
+        const bool right = mm < T::RPX;
+        const int x = right ? x0 - D + mm : x0 + (mm - T::RPX);
+        st_enter[u] = e == 1;
+        st_slot[u] = n < 2 * T::ENTRIES ? e * T::EVAL_SLOTS + (right ? mm + (mm >> 4) : T::RSLOTS + (mm - T::RPX)) : -1;
+        // byte offset inside the frame's two images; anything not addressable becomes "far out of range" (reads 0)
+        st_off[u] = (n < 2 * T::ENTRIES && x >= 0 && x < Wp) ? (right ? img_bytes : 0u) + 8u * (unsigned)x : 0xC0000000u;
+    }
+    v2u32 pf[2];
+    auto prefetch = [&](int leave_row, int enter_row) {
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            pf[u] = __builtin_amdgcn_raw_buffer_load_b64(Prs, (int)(st_off[u] + (unsigned)(st_enter[u] ? enter_row : leave_row) * row_pitch), 0, 0);
+    };
+    auto publish = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) if (st_slot[u] >= 0) stage[buf * 2 * T::EVAL_SLOTS + st_slot[u]] = pf[u];
+    };
+
+    v2s V[NCOL][NP], Lp[NCOL][NP];
+    // A row evaluation runs in two halves of the lane's disparity pairs, upper half first: pairs k >= KH need the lane's
+    // right pixels 0 .. MID, pairs k < KH the pixels MID .. 2NP, so only half of them are in registers at a time.
+    constexpr int KH = NP / 2, MID = 2 * (NP - KH);
+    auto add_cost = [&](const v2u32 (&r)[NR], const v2u32 (&l)[NCOL], int scale, int k_begin, int k_end) {
+        const v2s sc = splat(scale);
+#pragma unroll
+        for (int j = 0; j < NCOL; j++) {
+            const v2s g = splat(l[j].x & 0xff), g0 = splat((l[j].x >> 8) & 0xff), g1 = splat((l[j].x >> 16) & 0xff);
+            const v2s w = splat(l[j].y & 0xff), w0 = splat((l[j].y >> 8) & 0xff), w1 = splat((l[j].y >> 16) & 0xff);
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                if (k < k_begin || k >= k_end) continue;
+                const int ia = j - 2 * k + 2 * NP - 1; // slot 2k (lower d); slot 2k+1 is ia - 1
+                const v2s c = bt_pair(g, g0, g1, r[ia].x, r[ia - 1].x) + (bt_pair(w, w0, w1, r[ia].y, r[ia - 1].y) >> 2);
+                V[j][k] = c * sc + V[j][k];
+            }
+        }
+    };
+    // V += scale * (pixel cost of image row `row`), operands straight from memory (start of the stripe only)
+    const unsigned xl0 = 8u * (unsigned)(x0 + cb);
+    const unsigned xr0 = img_bytes + 8u * (unsigned)(x0 + cb - d0 - (2 * NP - 1)); // below zero only for unused halo columns
+    auto accum_global = [&](int row, int scale) {
+        const int so = row * (int)row_pitch; // uniform
+        v2u32 r[NR], l[NCOL];
+#pragma unroll
+        for (int j = 0; j < NCOL; j++) l[j] = __builtin_amdgcn_raw_buffer_load_b64(Prs, (int)(xl0 + 8u * j), so, 0);
+#pragma unroll
+        for (int i = 0; i <= MID; i++) r[i] = __builtin_amdgcn_raw_buffer_load_b64(Prs, (int)(xr0 + 8u * i), so, 0);
+        add_cost(r, l, scale, KH, NP);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = MID + 1; i < NR; i++) r[i] = __builtin_amdgcn_raw_buffer_load_b64(Prs, (int)(xr0 + 8u * i), so, 0);
+        add_cost(r, l, scale, 0, KH);
+    };
+    // the same from the staged pixels of evaluation e in stage buffer `buf`
+    const int p0 = cb + 2 * NP * (15 - lane16) + 1;   // index of the lane's first right pixel among the tile's RPX
+    const int p0_slot = p0 + (p0 >> 4), p0_wrap = 16 - (p0 & 15); // from its p0_wrap-th pixel on, one pad slot lies between
+    auto accum_staged = [&](int buf, int e, int scale) {
+        const v2u32* S = stage + (buf * 2 + e) * T::EVAL_SLOTS;
+        v2u32 r[NR], l[NCOL];
+#pragma unroll
+        for (int j = 0; j < NCOL; j++) l[j] = S[T::RSLOTS + cb + j];
+#pragma unroll
+        for (int i = 0; i <= MID; i++) r[i] = S[p0_slot + i + (i >= p0_wrap ? 1 : 0) + (i >= p0_wrap + 16 ? 1 : 0)];
+        add_cost(r, l, scale, KH, NP);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = MID + 1; i < NR; i++) r[i] = S[p0_slot + i + (i >= p0_wrap ? 1 : 0) + (i >= p0_wrap + 16 ? 1 : 0)];
+        add_cost(r, l, scale, 0, KH);
+    };
+
+    int m[NCOL];
+#pragma unroll
+    for (int j = 0; j < NCOL; j++) {
+        m[j] = 0;
+#pragma unroll
+        for (int k = 0; k < NP; k++) { V[j][k] = splat(0); Lp[j][k] = splat(0); }
+    }
+    // rows above the stripe top repeat its first row; past the last image row the last row repeats
+    if (rows > 1) prefetch(y0, min(y0 + 1 + SW2, H - 1)); // row 1: row 0 of the stripe leaves (it stood in for the rows above), row 1 + SW2 enters
+    accum_global(y0, SW2 + 1);
+    for (int dy = 1; dy <= SW2; dy++) accum_global(min(y0 + dy, H - 1), 1);
+
+    const int inf_pk = (32767 - P1) * 0x10001;
+    const int cmin = max(-xc0, 0), cmax = min(width1 - 1 - xc0, CV_COLS - 1);
+    constexpr int NC = NCOL + 2 * (SWC > 0 ? SWC : 1);
+    // The horizontal window clamps at the first / last cost column (tile columns cmin / cmax).  With a compile-time window
+    // the clamp is done on the writing side: the owner of an end column also writes its V into the SWC tile columns
+    // beyond it, columns outside [cmin, cmax] are not written by their owners, and every read is base + constant.
+    const int hbase = (cb - SWC) * CS + lane16;
+    const size_t rstride = (size_t)width1 * D;
+    const unsigned row_bytes = (unsigned)(rstride * sizeof(int16_t));
+    char* crow = reinterpret_cast<char*>(cost + ((size_t)b * srows + si.off[stripe]) * rstride);
+    char* arow = reinterpret_cast<char*>(agg + ((size_t)b * srows + si.off[stripe]) * rstride);
+    unsigned ocol[NCOL];
+#pragma unroll
+    for (int j = 0; j < NCOL; j++) {
+        const int c = cb + j, xc = xc0 + c;
+        ocol[j] = (c >= SW2 && c < CV_COLS - SW2 && xc < width1) ? (unsigned)((xc * D + d0) * (int)sizeof(int16_t)) : VO_BUF_SKIP;
+    }
+
+    for (int r = 0; r < rows; r++) {
+        const int y = y0 + r;
+        if (r > 0) {
+            // row r's pixels were published before the previous row's barrier
+            accum_staged(r & 1, 0, -1); // the row that leaves the window: y0 + max(r - SW2 - 1, 0)
+            accum_staged(r & 1, 1, 1);  // the row that enters it: min(y + SW2, H - 1)
+        }
+        int* buf = vt + (r & 1) * (CV_COLS * CS);
+#pragma unroll
+        for (int j = 0; j < NCOL; j++) {
+            const int c = cb + j;
+            if (SWC == 0 || (c >= cmin && c <= cmax)) {
+#pragma unroll
+                for (int k = 0; k < NP; k++) buf[c * CS + k * 16 + lane16] = as_int(V[j][k]);
+            }
+            if (SWC > 0 && (c == cmin || c == cmax)) { // rare: first and last tile of a row only
+                for (int e = 1; e <= SWC; e++) {
+                    if (c == cmin && c - e >= 0)
+                        for (int k = 0; k < NP; k++) buf[(c - e) * CS + k * 16 + lane16] = as_int(V[j][k]);
+                    if (c == cmax && c + e < CV_COLS)
+                        for (int k = 0; k < NP; k++) buf[(c + e) * CS + k * 16 + lane16] = as_int(V[j][k]);
+                }
+            }
+        }
+        // next row's pixels (requested a row ago) go to the other stage buffer, which was last read before the previous barrier
+        if (r + 1 < rows) publish((r + 1) & 1);
+        __syncthreads(); // one barrier per row: publishes V of this row and the staged pixels of the next
+        if (r + 2 < rows) prefetch(y0 + max(r + 2 - SW2 - 1, 0), min(y + 2 + SW2, H - 1));
+        v2s C[NCOL][NP];
+        if (SWC > 0) {
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                v2s col[NC];
+#pragma unroll
+                for (int i = 0; i < NC; i++) col[i] = as_v2s(buf[hbase + i * CS + k * 16]); // beyond the tile only for unused halo columns
+                v2s a = col[0];
+#pragma unroll
+                for (int i = 1; i <= 2 * SWC; i++) a += col[i];
+                C[0][k] = a;
+#pragma unroll
+                for (int j = 1; j < NCOL; j++) C[j][k] = C[j - 1][k] + col[j + 2 * SWC] - col[j - 1];
+                __builtin_amdgcn_sched_barrier(0); // keep the register columns apart: one column's 12 operands live at a time
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NP; k++) C[0][k] = splat(0);
+            for (int dx = -SW2; dx <= SW2; dx++) {
+                const int* p = buf + min(max(cb + dx, cmin), cmax) * CS + lane16;
+#pragma unroll
+                for (int k = 0; k < NP; k++) C[0][k] += as_v2s(p[k * 16]);
+            }
+#pragma unroll
+            for (int j = 1; j < NCOL; j++) {
+                const int* pa = buf + min(max(cb + j + SW2, cmin), cmax) * CS + lane16;
+                const int* ps = buf + min(max(cb + j - 1 - SW2, cmin), cmax) * CS + lane16;
+#pragma unroll
+                for (int k = 0; k < NP; k++) C[j][k] = C[j - 1][k] + as_v2s(pa[k * 16]) - as_v2s(ps[k * 16]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NCOL; j++) m[j] = path_step<NP>(C[j], Lp[j], m[j], P1, P2, inf_pk);
+        if (y >= si.out0[stripe]) {
+            const __amdgpu_buffer_rsrc_t crs = make_rsrc(crow, row_bytes), ars = make_rsrc(arow, row_bytes);
+#pragma unroll
+            for (int j = 0; j < NCOL; j++) {
+                store_pk_buf<NP>(crs, ocol[j], C[j]);
+                store_pk_buf<NP>(ars, ocol[j], Lp[j]);
+            }
+        }
+        crow += rstride * sizeof(int16_t); arow += rstride * sizeof(int16_t);
+    }
+}
+
 // ---------------------------------------------------------------- horizontal paths
 // The left-to-right path L_lr is needed again when the right-to-left pass forms S = L_rl + (L_lr + L_top), but a row of it
 // (width1 x D x 2 bytes) is far too large to keep on chip and storing it costs a volume write plus a volume read.
@@ -678,39 +907,59 @@ int run_sgbm(vo_ctx* c)
     { StageTimer st_(c, VO_ST_VPATH);
     // the reference's window (11x11, Source/VOClass.cpp:242) gets the instantiation with a compile-time half window
     const int swc = SH2 == 5 ? 5 : 0;
-    constexpr int NCOL = vo_cost_group_cols(NP);
-    constexpr int VO_COST_THREADS = vo_cost_threads(NP);
-    constexpr int TILE_COLS = (VO_COST_THREADS / 16) * NCOL;
-    // LDS: the double-buffered tile, plus as many ring slots as fit a third of a CU's 160 KB (three blocks per CU
-    // is what the kernel's register use allows at 96 disparities); the 512-thread blocks of the wide disparity ranges
-    // are alone on their CU (two wavefronts per SIMD at ~200 registers) and take nearly all of it
-#ifndef VO_COST_LDS_BUDGET
-#define VO_COST_LDS_BUDGET (52 * 1024)
-#endif
-    const size_t lds_budget = VO_COST_THREADS > 256 ? (size_t)150 * 1024 : (size_t)VO_COST_LDS_BUDGET;
-    const size_t tile_bytes = (size_t)2 * TILE_COLS * (16 * NP + 4) * sizeof(int);
-    const size_t slot_bytes = (size_t)(NCOL * NP / 2) * VO_COST_THREADS * sizeof(unsigned);
-    const int lds_slots = tile_bytes >= lds_budget ? 0
-                        : (int)std::min<size_t>((lds_budget - tile_bytes) / slot_bytes, (size_t)(2 * SH2 + 2));
-    const size_t lds = tile_bytes + lds_slots * slot_bytes;
-    const void* fn = swc ? reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 5, NCOL>) : reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 0, NCOL>);
-    // The dynamic-LDS ceiling of a kernel belongs to the device's copy of the code object and must cover every launch:
-    // `lds` varies with block_size (the ring slots are capped at block_size + 1), so the attribute is set to the budget
-    // itself (or the tile, if that alone exceeds it), which bounds `lds` for this instantiation, and raised if ever needed.
-    static std::atomic<int> lds_attr[64][2];
-    const int lds_cap = (int)std::max(lds_budget, tile_bytes);
-    if (lds > 48 * 1024 && lds_attr[c->device & 63][swc ? 1 : 0].load(std::memory_order_acquire) < lds_cap) {
-        VO_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_cap));
-        lds_attr[c->device & 63][swc ? 1 : 0].store(lds_cap, std::memory_order_release);
+    if constexpr (NP >= VO_COST_WIDE_NP) {
+        // wide disparity ranges: the 128-register form without a ring, two 512-thread blocks per CU
+        constexpr int TILE_COLS = WideTile<NP>::CV_COLS;
+        const size_t lds = WideTile<NP>::lds_bytes();
+        const void* fn = swc ? reinterpret_cast<const void*>(&cost_vpath_wide_kernel<NP, 5>) : reinterpret_cast<const void*>(&cost_vpath_wide_kernel<NP, 0>);
+        static std::atomic<int> wide_attr[64][2];
+        if (lds > 48 * 1024 && wide_attr[c->device & 63][swc ? 1 : 0].load(std::memory_order_acquire) < (int)lds) {
+            VO_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            wide_attr[c->device & 63][swc ? 1 : 0].store((int)lds, std::memory_order_release);
+        }
+        const int tile_out = TILE_COLS - 2 * SH2;
+        const dim3 grid((w1 + tile_out - 1) / tile_out, 4, n), blk(512);
+        if (swc)
+            hipLaunchKernelGGL((cost_vpath_wide_kernel<NP, 5>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
+                               SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg);
+        else
+            hipLaunchKernelGGL((cost_vpath_wide_kernel<NP, 0>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
+                               SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg);
+    } else {
+        constexpr int NCOL = vo_cost_group_cols(NP);
+        constexpr int VO_COST_THREADS = vo_cost_threads(NP);
+        constexpr int TILE_COLS = (VO_COST_THREADS / 16) * NCOL;
+        // LDS: the double-buffered tile, plus as many ring slots as fit a third of a CU's 160 KB (three blocks per CU
+        // is what the kernel's register use allows at 96 disparities); the 512-thread blocks of the wide disparity ranges
+        // are alone on their CU (two wavefronts per SIMD at ~200 registers) and take nearly all of it
+    #ifndef VO_COST_LDS_BUDGET
+    #define VO_COST_LDS_BUDGET (52 * 1024)
+    #endif
+        const size_t lds_budget = VO_COST_THREADS > 256 ? (size_t)150 * 1024 : (size_t)VO_COST_LDS_BUDGET;
+        const size_t tile_bytes = (size_t)2 * TILE_COLS * (16 * NP + 4) * sizeof(int);
+        const size_t slot_bytes = (size_t)(NCOL * NP / 2) * VO_COST_THREADS * sizeof(unsigned);
+        const int lds_slots = tile_bytes >= lds_budget ? 0
+                            : (int)std::min<size_t>((lds_budget - tile_bytes) / slot_bytes, (size_t)(2 * SH2 + 2));
+        const size_t lds = tile_bytes + lds_slots * slot_bytes;
+        const void* fn = swc ? reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 5, NCOL>) : reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 0, NCOL>);
+        // The dynamic-LDS ceiling of a kernel belongs to the device's copy of the code object and must cover every launch:
+        // `lds` varies with block_size (the ring slots are capped at block_size + 1), so the attribute is set to the budget
+        // itself (or the tile, if that alone exceeds it), which bounds `lds` for this instantiation, and raised if ever needed.
+        static std::atomic<int> lds_attr[64][2];
+        const int lds_cap = (int)std::max(lds_budget, tile_bytes);
+        if (lds > 48 * 1024 && lds_attr[c->device & 63][swc ? 1 : 0].load(std::memory_order_acquire) < lds_cap) {
+            VO_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_cap));
+            lds_attr[c->device & 63][swc ? 1 : 0].store(lds_cap, std::memory_order_release);
+        }
+        const int tile_out = TILE_COLS - 2 * SH2;
+        const dim3 grid((w1 + tile_out - 1) / tile_out, 4, n), blk(VO_COST_THREADS);
+        if (swc)
+            hipLaunchKernelGGL((cost_vpath_kernel<NP, 5, NCOL>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
+                               SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring, lds_slots);
+        else
+            hipLaunchKernelGGL((cost_vpath_kernel<NP, 0, NCOL>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
+                               SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring, lds_slots);
     }
-    const int tile_out = TILE_COLS - 2 * SH2;
-    const dim3 grid((w1 + tile_out - 1) / tile_out, 4, n), blk(VO_COST_THREADS);
-    if (swc)
-        hipLaunchKernelGGL((cost_vpath_kernel<NP, 5, NCOL>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
-                           SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring, lds_slots);
-    else
-        hipLaunchKernelGGL((cost_vpath_kernel<NP, 0, NCOL>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
-                           SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring, lds_slots);
     }
     const int nseg = vo_hpath_segments(c);
     { StageTimer st_(c, VO_ST_HPATH_FWD);

@@ -149,7 +149,7 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     const size_t B = c->p.max_batch, W = c->W, H = c->H, D = c->D, w1 = c->width1, F = c->p.max_features;
     c->own_pitch = (W + 63) & ~(size_t)63; c->own_fstride = c->own_pitch * H;
     CR(dalloc(&c->img_own, 4 * B * c->own_fstride));
-    CR(dalloc(&c->pre, B * 2 * H * (size_t)vo_pre_pitch(c) * 8));
+    CR(dalloc(&c->pre, B * 2 * H * (size_t)vo_pre_pitch(c) * 8 + 4096)); // slack: the wide cost kernel reads a few columns past the last row of halo tiles
     CR(dalloc(&c->ring, B * 4 * vo_cost_tiles(c) * (c->p.block_size + 1) * vo_cost_ring_dwords(c) * vo_cost_threads(c->D / 32)));
     CR(dalloc(&c->cost, B * c->srows * w1 * D));
     CR(dalloc(&c->agg, B * c->srows * w1 * D));

@@ -136,6 +136,10 @@ int vo_fail(vo_ctx* c, int code, const char* fmt, ...);
 #ifndef VO_COST_WIDE_THREADS
 #define VO_COST_WIDE_THREADS 512
 #endif
+// from this many disparity pairs per lane on (160 disparities), the cost kernel is the ring-less wide form (sgbm.hip)
+#ifndef VO_COST_WIDE_NP
+#define VO_COST_WIDE_NP 5
+#endif
 constexpr int vo_cost_group_cols(int pairs_per_lane) { return pairs_per_lane >= 6 ? 2 : 4; }
 constexpr int vo_cost_threads(int pairs_per_lane) { return pairs_per_lane >= 6 ? VO_COST_WIDE_THREADS : 256; }
 inline size_t vo_cost_tiles(const vo_ctx* c)
@@ -144,7 +148,7 @@ inline size_t vo_cost_tiles(const vo_ctx* c)
     return (size_t)((c->width1 + tile_out - 1) / tile_out);
 }
 // dwords of the pixel-cost ring per thread and slot (4 byte costs per dword)
-inline size_t vo_cost_ring_dwords(const vo_ctx* c) { return (size_t)vo_cost_group_cols(c->D / 32) * (c->D / 32) / 2; }
+inline size_t vo_cost_ring_dwords(const vo_ctx* c) { return c->D / 32 >= VO_COST_WIDE_NP ? 0 : (size_t)vo_cost_group_cols(c->D / 32) * (c->D / 32) / 2; }
 
 // horizontal paths: the left-to-right state is checkpointed every segment; a segment's columns live in registers,
 // so wide disparity ranges (more cells per lane) get shorter segments
