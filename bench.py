@@ -40,7 +40,7 @@ METRIC = "stereo frames/sec at 1241x376 (1/2/4/8 GPU) + achieved HBM GB/s vs roo
 # what bounds each kernel that has a byte model: the HBM roofline is read against the longest
 # kernel of the "hbm" class; the tracker is bound by vector-instruction issue and is reported beside it
 KERNEL_BOUND = {"sgbm_prefilter": "hbm", "sgbm_cost_vpath": "hbm", "sgbm_hpath_ckpt": "hbm", "sgbm_hpath_resolve": "hbm",
-                "sgbm_lrcheck": "hbm", "sgbm_median": "hbm", "lk": "valu"}
+                "sgbm_lrcheck_median": "hbm", "lk": "valu"}
 
 
 def log(*a):
@@ -91,8 +91,7 @@ def kernel_bytes(W, H, D, srows, nframes):
         "sgbm_cost_vpath": 2 * P * 8 + 2 * vol_h,       # prefiltered rows in; C and L_top out
         "sgbm_hpath_ckpt": vol_h + ckpt,                # C in; path state at segment starts out
         "sgbm_hpath_resolve": 2 * vol_h + ckpt + H * W * 4,   # C, L_top, checkpoints in; packed winner out
-        "sgbm_lrcheck": H * W * 4 + P * 2,
-        "sgbm_median": P * 2 + P * 2 + P * 4,
+        "sgbm_lrcheck_median": H * W * 4 + P * 2 + P * 2 + P * 4,   # packed winners in; pre-median, s16 and f32 maps out
         "lk": 4 * (pyr + 4 * pyr + pyr),                # 4 legs x (previous image + its derivatives + next image)
     }
     return {k: v * nframes for k, v in per.items()}
@@ -272,8 +271,8 @@ def parse_args(argv):
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--inflight", type=int, default=0,
-                    help="contexts taking turns (overlaps host PnP with GPU work; default: 3 at KITTI shape, 2 at 4K, "
-                         "where a context holds 5.5 GB per frame pair)")
+                    help="contexts taking turns (overlaps host PnP with GPU work; default 3; at 4K a context holds "
+                         "5.5 GB per frame pair)")
     ap.add_argument("--upload", action="store_true",
                     help="re-upload the batch's images from host memory before every step of the timed region (PCIe-inclusive rate; "
                          "the headline value is measured without it, inputs resident in HBM)")
@@ -304,7 +303,7 @@ def main(argv=None):
     if args.batch <= 0:
         args.batch = 8 if args.workload == "4k" else 16
     if args.inflight <= 0:
-        args.inflight = 2 if args.workload == "4k" else 3
+        args.inflight = 3
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

@@ -159,7 +159,7 @@ int vo_set_features(vo_ctx* ctx, int b, const vo_point2f* pts, int n);
 
 /* FAST corners of ONE image, allocating nothing.  No counterpart in the reference: it exists for callers that cannot
  * allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same
- * kernels and same results as vo_detect_fast + vo_get_features; the kernels' scratch (score map, row counts, row offsets)
+ * kernels and same results as vo_detect_fast + vo_get_features; the kernels' scratch (score map, row counts)
  * lives in a fixed device array of the library instead of a context, so the image is limited to 2^21 pixels and 4096
  * rows (VO_ERR_CAPACITY beyond; the text is in vo_create_error()).  img_dev, out_dev (cap points) and n_out_dev (one int:
  * min(number of corners, cap)) are device pointers on the CURRENT device; the work is enqueued on `stream` (a hipStream_t,
@@ -231,8 +231,8 @@ int vo_pyramid_info(vo_ctx* ctx, int level, int* w, int* h, int* max_level);
  * calls: how many times each stage ran since the last reset.  No counterpart in the reference. */
 #define VO_NUM_STAGES 16
 typedef enum {
-    VO_ST_PREFILTER = 0, /* 1: not in use */ VO_ST_VPATH = 2, VO_ST_HPATH_FWD = 3, VO_ST_HPATH_BWD = 4, VO_ST_LRCHECK = 5,
-    VO_ST_MEDIAN = 6, VO_ST_FAST = 7, VO_ST_PYRAMID = 8, VO_ST_LK = 9, VO_ST_FILTER = 10, VO_ST_TRIANGULATE = 11,
+    VO_ST_PREFILTER = 0, /* 1: not in use */ VO_ST_VPATH = 2, VO_ST_HPATH_FWD = 3, VO_ST_HPATH_BWD = 4, VO_ST_LRCHECK = 5 /* consistency check + median */,
+    /* 6: not in use */ VO_ST_FAST = 7, VO_ST_PYRAMID = 8, VO_ST_LK = 9, VO_ST_FILTER = 10, VO_ST_TRIANGULATE = 11,
     VO_ST_PNP_SCORE = 12, VO_ST_PNP_HOST = 13, VO_ST_STEP_WALL = 14
 } vo_stage;
 int vo_set_timing(vo_ctx* ctx, int enable);

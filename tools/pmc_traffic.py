@@ -15,7 +15,7 @@ import re
 import sys
 
 STAGE = {"prefilter_kernel": "sgbm_prefilter", "cost_vpath_kernel": "sgbm_cost_vpath", "hpath_ckpt_kernel": "sgbm_hpath_ckpt",
-         "hpath_resolve_kernel": "sgbm_hpath_resolve", "lrcheck_kernel": "sgbm_lrcheck", "median_kernel": "sgbm_median",
+         "hpath_resolve_kernel": "sgbm_hpath_resolve", "lrmedian_kernel": "sgbm_lrcheck_median",
          "lk_row_kernel": "lk"}
 
 

@@ -6,9 +6,9 @@
 //                       turned into a bright and a dark 16-bit mask, "9 contiguous" is a shift-and-AND test,
 //                       the corner score is the closed form max(t, max_arc min(d), max_arc min(-d)) - 1.
 //  fast_count_kernel  : per image row, number of pixels whose score is a strict 3x3 maximum.
-//  fast_scan_kernel   : exclusive scan of the row counts (one block per image).
-//  fast_write_kernel  : per image row, wavefront ballot + prefix popcount gives every keypoint its rank,
-//                       so the output order is y-major, x-minor, identical on every run.
+//  fast_write_kernel  : per image row, the sum of the counts of the rows above is the row's offset; wavefront ballot +
+//                       prefix popcount gives every keypoint its rank, so the output order is y-major, x-minor,
+//                       identical on every run.
 #include "vo_ctx.h"
 #include <string.h>
 #include <algorithm>
@@ -121,38 +121,29 @@ __global__ __launch_bounds__(256) void fast_count_kernel(const uint8_t* __restri
     if (threadIdx.x == 0) row_count[b * H + y] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-__global__ __launch_bounds__(256) void fast_scan_kernel(const int* __restrict__ row_count, int H, int cap,
-                                                        int* __restrict__ row_off, int* __restrict__ n_feat)
-{
-    __shared__ int part[256];
-    const int b = blockIdx.x;
-    const int per = (H + 255) / 256;
-    const int y0 = threadIdx.x * per, y1 = min(y0 + per, H);
-    int s = 0;
-    for (int y = y0; y < y1; y++) s += row_count[b * H + y];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int acc = 0;
-        for (int i = 0; i < 256; i++) { int t = part[i]; part[i] = acc; acc += t; }
-        n_feat[b] = min(acc, cap);
-    }
-    __syncthreads();
-    int acc = part[threadIdx.x];
-    for (int y = y0; y < y1; y++) { row_off[b * H + y] = acc; acc += row_count[b * H + y]; }
-}
-
+// Per image row: its offset in the output is the number of keypoints in the rows above (summed by the block from the row
+// counts: at most a few thousand small reads), then wavefront ballot + prefix popcount gives every keypoint its rank.
+// The block of the last row also publishes the total.
 __global__ __launch_bounds__(256) void fast_write_kernel(const uint8_t* __restrict__ score, int W, int H, int nms, int cap,
-                                                         const int* __restrict__ row_count, const int* __restrict__ row_off,
-                                                         vo_point2f* __restrict__ feat)
+                                                         const int* __restrict__ row_count, vo_point2f* __restrict__ feat,
+                                                         int* __restrict__ n_feat)
 {
     __shared__ int wcnt[4];
+    __shared__ int wsum[4];
     const int y = blockIdx.x, b = blockIdx.y;
-    if (row_count[b * H + y] == 0) return; // uniform per block
+    const int mine = row_count[b * H + y];
+    if (mine == 0 && y != H - 1) return; // uniform per block
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int above = 0;
+    for (int r = threadIdx.x; r < y; r += 256) above += row_count[b * H + r];
+    for (int o = 32; o > 0; o >>= 1) above += __shfl_down(above, o);
+    if (lane == 0) wsum[wave] = above;
+    __syncthreads();
+    int base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (y == H - 1 && threadIdx.x == 0) n_feat[b] = min(base + mine, cap);
+    if (mine == 0) return;
     const uint8_t* s = score + (size_t)b * H * W;
     vo_point2f* out = feat + (size_t)b * cap;
-    int base = row_off[b * H + y];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int xs = 3; xs < W - 3; xs += 256) {
         int x = xs + threadIdx.x;
         bool k = x < W - 3 && is_keypoint(s, W, x, y, nms);
@@ -181,9 +172,8 @@ int launch_fast(vo_ctx* c)
     hipLaunchKernelGGL(fast_score_kernel, g1, b1, 0, c->stream, c->img[0], c->pitch, c->fstride, W, H,
                        c->p.fast_threshold, c->p.fast_nms, c->score);
     hipLaunchKernelGGL(fast_count_kernel, dim3(H, n), dim3(256), 0, c->stream, c->score, W, H, c->p.fast_nms, c->row_count);
-    hipLaunchKernelGGL(fast_scan_kernel, dim3(n), dim3(256), 0, c->stream, c->row_count, H, c->p.max_features, c->row_off, c->n_feat);
     hipLaunchKernelGGL(fast_write_kernel, dim3(H, n), dim3(256), 0, c->stream, c->score, W, H, c->p.fast_nms,
-                       c->p.max_features, c->row_count, c->row_off, c->feat);
+                       c->p.max_features, c->row_count, c->feat, c->n_feat);
     VO_HIP(c, hipGetLastError());
     return VO_OK;
 }
@@ -196,7 +186,7 @@ int launch_fast(vo_ctx* c)
 constexpr size_t kNoAllocMaxPixels = (size_t)1 << 21;   // 2 Mi pixels (e.g. 1920 x 1080); KITTI frames are 0.47 Mi
 constexpr int kNoAllocMaxRows = 4096;
 constexpr size_t kNoAllocScoreBytes = kNoAllocMaxPixels;
-constexpr size_t kNoAllocBytes = kNoAllocScoreBytes + 2 * (size_t)kNoAllocMaxRows * sizeof(int);
+constexpr size_t kNoAllocBytes = kNoAllocScoreBytes + (size_t)kNoAllocMaxRows * sizeof(int);
 static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
 
 static std::mutex g_scratch_mu;
@@ -225,17 +215,15 @@ extern "C" int vo_detect_fast_noalloc(const uint8_t* img_dev, int width, int hei
     }
     uint8_t* score = base;
     int* row_count = reinterpret_cast<int*>(base + kNoAllocScoreBytes);
-    int* row_off = row_count + kNoAllocMaxRows;
     hipStream_t st = static_cast<hipStream_t>(stream);
     threshold = std::min(std::max(threshold, 0), 255);
     // every word of the scratch that a kernel reads was written by an earlier kernel of this same call (the score kernel
-    // writes all width x height scores, the count kernel all `height` counts, the scan all offsets), so nothing has to
+    // writes all width x height scores, the count kernel all `height` counts), so nothing has to
     // start at zero and what the previous call left behind is never seen
     dim3 g1((width + TILE_W - 1) / TILE_W, (height + TILE_H - 1) / TILE_H, 1), b1(TILE_W, 4);
     hipLaunchKernelGGL(fast_score_kernel, g1, b1, 0, st, img_dev, stride, (size_t)0, width, height, threshold, nms, score);
     hipLaunchKernelGGL(fast_count_kernel, dim3(height, 1), dim3(256), 0, st, score, width, height, nms, row_count);
-    hipLaunchKernelGGL(fast_scan_kernel, dim3(1), dim3(256), 0, st, row_count, height, cap, row_off, n_out_dev);
-    hipLaunchKernelGGL(fast_write_kernel, dim3(height, 1), dim3(256), 0, st, score, width, height, nms, cap, row_count, row_off, out_dev);
+    hipLaunchKernelGGL(fast_write_kernel, dim3(height, 1), dim3(256), 0, st, score, width, height, nms, cap, row_count, out_dev, n_out_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vo_fail(nullptr, VO_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return VO_OK;

@@ -6,11 +6,11 @@
 // buildOpticalFlowPyramid keeps), its Scharr derivative (Ix, Iy int16 pairs) with a zero border of the same
 // width, so the tracker never branches on image edges.
 //
-//  level0_kernel   : copies an input image into its bordered level-0 slot.
-//  pyrdown_kernel  : separable 5-tap [1 4 6 4 1] in LDS: horizontal sums of a source strip, then vertical,
-//                    (sum + 128) >> 8; reads the bordered previous level, so no edge cases.
-//  border_kernel   : fills the border of a level by reflection.
-//  scharr_kernel   : 3x3 Scharr of a level (from its bordered image), zero outside.
+//  level0_scharr_kernel  : copies an input image into its bordered level-0 slot and writes its 3x3 Scharr
+//                          derivative (zero outside the image) in the same pass.
+//  pyrdown_scharr_kernel : one launch per further level: 5x5 [1 4 6 4 1]^2 reduction ((sum + 128) >> 8) of the bordered
+//                          previous level for a tile of the bordered new level (border pixels evaluate the position
+//                          they reflect to), staged in LDS with a one-pixel halo, written with its Scharr derivative.
 //  lk_row_kernel   : 16 lanes per feature (4 features per wavefront) run all four legs LT1->RT1->RT2->LT2->LT1
 //                    and all pyramid levels; a lane owns one or two window rows, the 2x2 structure tensor and
 //                    the mismatch vector are accumulated in integers (order independent) with 16-bit dot
@@ -39,99 +39,92 @@ struct PyrArgs { int nlevels, border, img_per_b; LevelArgs lv[VO_MAX_LEVELS]; un
 // row (levels are stored with a pitch that is a multiple of 16, so that is one aligned dword of the level).
 constexpr int PX_T = 64, PX_R = 4, PX_N = 4;
 
-__global__ __launch_bounds__(256) void level0_kernel(const uint8_t* i0, const uint8_t* i1, const uint8_t* i2, const uint8_t* i3,
-                                                     size_t pitch, size_t fstride, PyrArgs pa, uint8_t* __restrict__ pyr)
+// Level 0 and its derivative in one pass over the bordered level: a thread owns 4 adjacent pixels of a row, reads the 3 x 6
+// source pixels around them (reflected at the image edge, which is what the level's own border holds) and writes 4 image
+// bytes and 4 (Ix, Iy) pairs.
+__device__ __forceinline__ void scharr4(const int (&c)[3][PX_N + 2], int px0, int border, int w, bool row_inside, int4& o)
+{
+    int v[PX_N];
+#pragma unroll
+    for (int j = 0; j < PX_N; j++) {
+        const int x = px0 + j - border;
+        const int ix = ((c[0][j + 2] + c[2][j + 2]) * 3 + c[1][j + 2] * 10) - ((c[0][j] + c[2][j]) * 3 + c[1][j] * 10);
+        const int iy = ((c[2][j] - c[0][j]) + (c[2][j + 2] - c[0][j + 2])) * 3 + (c[2][j + 1] - c[0][j + 1]) * 10;
+        v[j] = (row_inside && x >= 0 && x < w) ? ((ix & 0xffff) | (iy << 16)) : 0;
+    }
+    o = make_int4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ __launch_bounds__(256) void level0_scharr_kernel(const uint8_t* i0, const uint8_t* i1, const uint8_t* i2, const uint8_t* i3,
+                                                            size_t pitch, size_t fstride, PyrArgs pa, uint8_t* __restrict__ pyr,
+                                                            int16_t* __restrict__ der)
 {
     const int px0 = (blockIdx.x * PX_T + (threadIdx.x & (PX_T - 1))) * PX_N, py = blockIdx.y * PX_R + (threadIdx.x / PX_T);
     const int b = blockIdx.z / pa.img_per_b, which = blockIdx.z % pa.img_per_b;
     const LevelArgs L = pa.lv[0];
     if (px0 >= L.pitch || py >= L.rows) return;
     const uint8_t* src = (which == 0 ? i0 : which == 1 ? i1 : which == 2 ? i2 : i3) + (size_t)b * fstride;
-    const uint8_t* row = src + (size_t)reflect101(py - pa.border, L.h) * pitch;
-    unsigned v = 0;
-#pragma unroll
-    for (int j = 0; j < PX_N; j++) {
-        const int x = reflect101(min(px0 + j, L.w + 2 * pa.border - 1) - pa.border, L.w);
-        v |= (unsigned)row[x] << (8 * j);
-    }
-    *reinterpret_cast<unsigned*>(pyr + (size_t)blockIdx.z * pa.pyr_bytes + L.img_off + (size_t)py * L.pitch + px0) = v;
-}
-
-constexpr int PD_TX = 32, PD_TY = 8;
-
-__global__ __launch_bounds__(256) void pyrdown_kernel(PyrArgs pa, int level, uint8_t* __restrict__ pyr)
-{
-    __shared__ int hs[2 * PD_TY + 3][PD_TX];
-    const LevelArgs S = pa.lv[level - 1], Dl = pa.lv[level];
-    uint8_t* base = pyr + (size_t)blockIdx.z * pa.pyr_bytes;
-    const uint8_t* src = base + S.img_off + (size_t)pa.border * S.pitch + pa.border; // interior origin
-    uint8_t* dst = base + Dl.img_off + (size_t)pa.border * Dl.pitch + pa.border;
-    const int x0 = blockIdx.x * PD_TX, y0 = blockIdx.y * PD_TY;
-    const int tx = threadIdx.x & (PD_TX - 1), ty = threadIdx.x / PD_TX; // 32 x 8
-    const int x = x0 + tx;
-    // horizontal pass over source rows 2*y0-2 .. 2*y0+2*PD_TY (19 rows); rows/cols outside the level come from its border
-    for (int r = ty; r < 2 * PD_TY + 3; r += PD_TY) {
-        int sy = min(2 * y0 - 2 + r, S.h + 1); // rows beyond h+1 are never used by a valid output row
-        int sx = min(2 * x, S.w + 1);
-        const uint8_t* p = src + (ptrdiff_t)sy * S.pitch + sx;
-        hs[r][tx] = p[-2] + 4 * p[-1] + 6 * p[0] + 4 * p[1] + p[2];
-    }
-    __syncthreads();
-    const int y = y0 + ty;
-    if (x < Dl.w && y < Dl.h) {
-        int r = 2 * ty;
-        int s = hs[r][tx] + 4 * hs[r + 1][tx] + 6 * hs[r + 2][tx] + 4 * hs[r + 3][tx] + hs[r + 4][tx];
-        dst[(size_t)y * Dl.pitch + x] = (uint8_t)((s + 128) >> 8);
-    }
-}
-
-__global__ __launch_bounds__(256) void border_kernel(PyrArgs pa, int level, uint8_t* __restrict__ pyr)
-{
-    const LevelArgs L = pa.lv[level];
-    const int px = blockIdx.x * 256 + threadIdx.x, py = blockIdx.y;
-    if (px >= L.pitch) return;
-    const int x = px - pa.border, y = py - pa.border;
-    if (x >= 0 && x < L.w && y >= 0 && y < L.h) return;
-    uint8_t* img = pyr + (size_t)blockIdx.z * pa.pyr_bytes + L.img_off;
-    int sx = reflect101(min(x, L.w + pa.border - 1), L.w), sy = reflect101(y, L.h);
-    img[(size_t)py * L.pitch + px] = img[(size_t)(sy + pa.border) * L.pitch + sx + pa.border];
-}
-
-__global__ __launch_bounds__(256) void scharr_kernel(PyrArgs pa, int level, const uint8_t* __restrict__ pyr, int16_t* __restrict__ der)
-{
-    const LevelArgs L = pa.lv[level];
-    const int px0 = (blockIdx.x * PX_T + (threadIdx.x & (PX_T - 1))) * PX_N, py = blockIdx.y * PX_R + (threadIdx.x / PX_T);
-    if (px0 >= L.pitch || py >= L.rows) return;
     const int y = py - pa.border;
-    int4 o = make_int4(0, 0, 0, 0);
-    // any of the 4 pixels inside the image?  (then rows py-1, py+1 and columns px0-1 .. px0+4 lie in the bordered level)
-    if (y >= 0 && y < L.h && px0 + PX_N - 1 >= pa.border && px0 < pa.border + L.w) {
-        const uint8_t* p = pyr + (size_t)blockIdx.z * pa.pyr_bytes + L.img_off + (size_t)py * L.pitch + px0;
-        const int P = L.pitch;
-        int c[3][PX_N + 2]; // columns px0-1 .. px0+4 of rows py-1, py, py+1
+    int c[3][PX_N + 2]; // bordered columns px0-1 .. px0+4 of rows py-1, py, py+1
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
-            const uint8_t* q = p + (r - 1) * P;
-            const unsigned cur = *reinterpret_cast<const unsigned*>(q);
-            const unsigned prv = px0 >= PX_N ? *reinterpret_cast<const unsigned*>(q - 4) : 0u;
-            const unsigned nxt = px0 + PX_N < L.pitch ? *reinterpret_cast<const unsigned*>(q + 4) : 0u;
-            c[r][0] = prv >> 24;
+    for (int r = 0; r < 3; r++) {
+        const uint8_t* row = src + (size_t)reflect101(y - 1 + r, L.h) * pitch;
 #pragma unroll
-            for (int j = 0; j < PX_N; j++) c[r][1 + j] = (cur >> (8 * j)) & 0xff;
-            c[r][PX_N + 1] = nxt & 0xff;
-        }
-        int v[PX_N];
-#pragma unroll
-        for (int j = 0; j < PX_N; j++) {
-            const int x = px0 + j - pa.border;
-            const int ix = ((c[0][j + 2] + c[2][j + 2]) * 3 + c[1][j + 2] * 10) - ((c[0][j] + c[2][j]) * 3 + c[1][j] * 10);
-            const int iy = ((c[2][j] - c[0][j]) + (c[2][j + 2] - c[0][j + 2])) * 3 + (c[2][j + 1] - c[0][j + 1]) * 10;
-            v[j] = (x >= 0 && x < L.w) ? ((ix & 0xffff) | (iy << 16)) : 0;
-        }
-        o = make_int4(v[0], v[1], v[2], v[3]);
+        for (int i = 0; i < PX_N + 2; i++)
+            c[r][i] = row[reflect101(min(px0 - 1 + i, L.w + 2 * pa.border - 1) - pa.border, L.w)];
     }
+    const unsigned v = (unsigned)c[1][1] | ((unsigned)c[1][2] << 8) | ((unsigned)c[1][3] << 16) | ((unsigned)c[1][4] << 24);
+    *reinterpret_cast<unsigned*>(pyr + (size_t)blockIdx.z * pa.pyr_bytes + L.img_off + (size_t)py * L.pitch + px0) = v;
+    int4 o;
+    scharr4(c, px0, pa.border, L.w, y >= 0 && y < L.h, o);
     int* out = reinterpret_cast<int*>(der + (size_t)blockIdx.z * pa.der_elems + L.der_off);
     *reinterpret_cast<int4*>(out + (size_t)py * L.pitch + px0) = o;
+}
+
+// One pyramid level from the previous one, border and derivative included, in one launch.  A block owns a PD_TX x PD_TY
+// tile of the BORDERED level.  The value of a bordered pixel is the 5x5 [1 4 6 4 1] x [1 4 6 4 1] reduction at the position
+// it reflects to inside the level ((sum + 128) >> 8; the taps read the bordered previous level, so they need no edge
+// cases); the tile is evaluated with a one-pixel halo into LDS, then written out together with its Scharr derivative.
+constexpr int PD_TX = 64, PD_TY = 4;
+
+__global__ __launch_bounds__(256) void pyrdown_scharr_kernel(PyrArgs pa, int level, uint8_t* __restrict__ pyr, int16_t* __restrict__ der)
+{
+    __shared__ int val[PD_TY + 2][PD_TX + 3]; // rows py0-1 .. py0+PD_TY, bordered columns px_tile-1 .. px_tile+PD_TX
+    const LevelArgs S = pa.lv[level - 1], Dl = pa.lv[level];
+    uint8_t* base = pyr + (size_t)blockIdx.z * pa.pyr_bytes;
+    const uint8_t* src = base + S.img_off + (size_t)pa.border * S.pitch + pa.border; // interior origin of the previous level
+    const int pxt = blockIdx.x * PD_TX, py0 = blockIdx.y * PD_TY;
+    for (int i = threadIdx.x; i < (PD_TY + 2) * (PD_TX + 2); i += 256) {
+        const int ry = i / (PD_TX + 2), rx = i - ry * (PD_TX + 2);
+        const int x = reflect101(min(pxt - 1 + rx, Dl.w + 2 * pa.border - 1) - pa.border, Dl.w);
+        const int y = reflect101(py0 - 1 + ry - pa.border, Dl.h);
+        const uint8_t* p = src + (ptrdiff_t)(2 * y - 2) * S.pitch + (2 * x - 2);
+        int s = 0;
+#pragma unroll
+        for (int dy = 0; dy < 5; dy++) {
+            const int wy = dy == 0 || dy == 4 ? 1 : dy == 2 ? 6 : 4;
+            const uint8_t* q = p + dy * S.pitch;
+            s += wy * (q[0] + 4 * q[1] + 6 * q[2] + 4 * q[3] + q[4]);
+        }
+        val[ry][rx] = (s + 128) >> 8;
+    }
+    __syncthreads();
+    // 64 threads x 4 rows; a thread owns one pixel column of the tile here (the tile is 64 wide): 4 rows x 64 columns
+    const int tx = threadIdx.x & (PD_TX - 1), ty = threadIdx.x / PD_TX;
+    const int px = pxt + tx, py = py0 + ty;
+    if (px >= Dl.pitch || py >= Dl.rows) return;
+    base[Dl.img_off + (size_t)py * Dl.pitch + px] = (uint8_t)val[ty + 1][tx + 1];
+    const int x = px - pa.border, y = py - pa.border;
+    int d = 0;
+    if (x >= 0 && x < Dl.w && y >= 0 && y < Dl.h) {
+        const int a0 = val[ty][tx], a1 = val[ty][tx + 1], a2 = val[ty][tx + 2];
+        const int b0 = val[ty + 1][tx], b2 = val[ty + 1][tx + 2];
+        const int c0 = val[ty + 2][tx], c1 = val[ty + 2][tx + 1], c2 = val[ty + 2][tx + 2];
+        const int ix = ((a2 + c2) * 3 + b2 * 10) - ((a0 + c0) * 3 + b0 * 10);
+        const int iy = ((c0 - a0) + (c2 - a2)) * 3 + (c1 - a1) * 10;
+        d = (ix & 0xffff) | (iy << 16);
+    }
+    reinterpret_cast<int*>(der + (size_t)blockIdx.z * pa.der_elems + Dl.der_off)[(size_t)py * Dl.pitch + px] = d;
 }
 
 #define DPP_ADD(v, ctrl) ((v) + __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, false))
@@ -490,16 +483,11 @@ int launch_pyramids(vo_ctx* c)
     StageTimer st_(c, VO_ST_PYRAMID);
     const PyrArgs pa = make_pyr_args(c);
     const int nimg = c->seq_mode ? 2 * (c->n + 1) : 4 * c->n;
-    auto px_grid = [&](int l) { return dim3((pa.lv[l].pitch / PX_N + PX_T - 1) / PX_T, (pa.lv[l].rows + PX_R - 1) / PX_R, nimg); };
-    hipLaunchKernelGGL(level0_kernel, px_grid(0), dim3(256), 0, c->stream,
-                       c->img[0], c->img[1], c->img[2], c->img[3], c->pitch, c->fstride, pa, c->pyr);
-    for (int l = 1; l <= c->nlevels; l++) {
-        hipLaunchKernelGGL(pyrdown_kernel, dim3((pa.lv[l].w + PD_TX - 1) / PD_TX, (pa.lv[l].h + PD_TY - 1) / PD_TY, nimg), dim3(256), 0,
-                           c->stream, pa, l, c->pyr);
-        hipLaunchKernelGGL(border_kernel, dim3((pa.lv[l].pitch + 255) / 256, pa.lv[l].rows, nimg), dim3(256), 0, c->stream, pa, l, c->pyr);
-    }
-    for (int l = 0; l <= c->nlevels; l++)
-        hipLaunchKernelGGL(scharr_kernel, px_grid(l), dim3(256), 0, c->stream, pa, l, c->pyr, c->der);
+    hipLaunchKernelGGL(level0_scharr_kernel, dim3((pa.lv[0].pitch / PX_N + PX_T - 1) / PX_T, (pa.lv[0].rows + PX_R - 1) / PX_R, nimg), dim3(256), 0,
+                       c->stream, c->img[0], c->img[1], c->img[2], c->img[3], c->pitch, c->fstride, pa, c->pyr, c->der);
+    for (int l = 1; l <= c->nlevels; l++)
+        hipLaunchKernelGGL(pyrdown_scharr_kernel, dim3((pa.lv[l].pitch + PD_TX - 1) / PD_TX, (pa.lv[l].rows + PD_TY - 1) / PD_TY, nimg), dim3(256), 0,
+                           c->stream, pa, l, c->pyr, c->der);
     VO_HIP(c, hipGetLastError());
     return VO_OK;
 }

@@ -16,9 +16,9 @@
 //                     First pass: L_lr, keeping its state at segment starts.  Second pass, right to left: L_lr of a
 //                     segment replayed into registers, L_rl, S = sum of the three paths, winner-take-all with
 //                     OpenCV's tie rule, sub-pixel fit, packed (minS, d16) per pixel.
-//  lrcheck_kernel   : per image row, right-view disparity by an order-independent LDS atomic-min scatter
-//                     (smallest cost, then largest x), then the two-sided consistency test.
-//  median_kernel    : 3x3 median (replicated border) on the s16 map, plus the /16 float map.
+//  lrmedian_kernel  : per image row, right-view disparity by an order-independent LDS atomic-min scatter
+//                     (smallest cost, then largest x) and the two-sided consistency test for the row and its two
+//                     neighbours, then the 3x3 median (replicated border) on the s16 map, plus the /16 float map.
 #include "vo_ctx.h"
 #include <string.h>
 #include <algorithm>
@@ -819,69 +819,76 @@ __global__ __launch_bounds__(64) void hpath_resolve_kernel(const int16_t* __rest
     }
 }
 
-// ---------------------------------------------------------------- right-view disparity + consistency check
-__global__ __launch_bounds__(256) void lrcheck_kernel(const int32_t* __restrict__ wta, int W, int H, int width1, int srows,
-                                                      StripeInfo si, int stripe_sz, int disp12, int16_t* __restrict__ disp_pre)
-{
-    extern __shared__ unsigned key[]; // [W]
-    const int y = blockIdx.x, b = blockIdx.y;
-    const int stripe = min(y / stripe_sz, 3);
-    const int sr = si.off[stripe] + (y - si.y0[stripe]);
-    const int32_t* w = wta + ((size_t)b * srows + sr) * W;
-    const int minX1 = W - width1;
-    for (int x = threadIdx.x; x < W; x += 256) key[x] = 0xffffffffu;
-    __syncthreads();
-    for (int x = minX1 + threadIdx.x; x < W; x += 256) {
-        int v = w[x];
-        int minS = v >> 16, d16 = (short)(v & 0xffff);
-        int bestd = (d16 + 7) >> 4;
-        if (minS != 32767)
-            atomicMin(&key[x - bestd], ((unsigned)(minS + 32768) << 16) | (unsigned)(0xffff - x));
-    }
-    __syncthreads();
-    int16_t* out = disp_pre + ((size_t)b * H + y) * W;
-    for (int x = threadIdx.x; x < W; x += 256) {
-        int res = -16;
-        if (x >= minX1) {
-            int d1 = (short)(w[x] & 0xffff);
-            int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
-            int _x = x - _d, x_ = x - d_;
-            bool bad = true;
-            {
-                unsigned k = key[_x]; // 0 <= _x because _d <= x - minX1 + ... (d < D <= minX1)
-                int d2 = k == 0xffffffffu ? -16 : (0xffff - (int)(k & 0xffff)) - _x;
-                bad = bad && d2 >= 0 && abs(d2 - _d) > disp12;
-            }
-            {
-                bool inr = x_ >= 0;
-                unsigned k = inr ? key[x_] : 0xffffffffu;
-                int d2 = k == 0xffffffffu ? -16 : (0xffff - (int)(k & 0xffff)) - x_;
-                bad = bad && inr && d2 >= 0 && abs(d2 - d_) > disp12;
-            }
-            res = bad ? -16 : d1;
-        }
-        out[x] = (int16_t)res;
-    }
-}
-
-// ---------------------------------------------------------------- 3x3 median
+// ---------------------------------------------------------------- right-view disparity + consistency check + 3x3 median
+// One block per image row y.  The median needs the checked rows y-1, y, y+1 (replicated at the image border), so the block
+// runs the consistency check of those three rows itself (a row's check is a scatter and a gather over W packed winners,
+// far cheaper than a launch): per row, the right-view disparity by an order-independent LDS atomic-min scatter (smallest
+// cost, then largest x), then the two-sided test.  The centre row is also kept as the pre-median map.
 #define CSWAP(a, b) { int t_ = min(a, b); b = max(a, b); a = t_; }
-__global__ __launch_bounds__(256) void median_kernel(const int16_t* __restrict__ src, int W, int H, int16_t* __restrict__ dst, float* __restrict__ dstf)
+__global__ __launch_bounds__(256) void lrmedian_kernel(const int32_t* __restrict__ wta, int W, int H, int width1, int srows,
+                                                       StripeInfo si, int stripe_sz, int disp12, int16_t* __restrict__ disp_pre,
+                                                       int16_t* __restrict__ dst, float* __restrict__ dstf)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
-    if (x >= W) return;
-    const int16_t* s = src + (size_t)b * H * W;
-    const int x0 = max(x - 1, 0), x2 = min(x + 1, W - 1), y0 = max(y - 1, 0), y2 = min(y + 1, H - 1);
-    int p0 = s[(size_t)y0 * W + x0], p1 = s[(size_t)y0 * W + x], p2 = s[(size_t)y0 * W + x2];
-    int p3 = s[(size_t)y * W + x0], p4 = s[(size_t)y * W + x], p5 = s[(size_t)y * W + x2];
-    int p6 = s[(size_t)y2 * W + x0], p7 = s[(size_t)y2 * W + x], p8 = s[(size_t)y2 * W + x2];
-    CSWAP(p1, p2); CSWAP(p4, p5); CSWAP(p7, p8); CSWAP(p0, p1); CSWAP(p3, p4); CSWAP(p6, p7);
-    CSWAP(p1, p2); CSWAP(p4, p5); CSWAP(p7, p8); CSWAP(p0, p3); CSWAP(p5, p8); CSWAP(p4, p7);
-    CSWAP(p3, p6); CSWAP(p1, p4); CSWAP(p2, p5); CSWAP(p4, p7); CSWAP(p4, p2); CSWAP(p6, p4);
-    CSWAP(p4, p2);
-    size_t o = ((size_t)b * H + y) * W + x;
-    dst[o] = (int16_t)p4;
-    dstf[o] = (float)p4 * (1.0f / 16.0f);
+    extern __shared__ unsigned lm_sm[]; // key[W], then three rows of checked disparities (int16, W rounded up to 2)
+    unsigned* key = lm_sm;
+    const int Wr = (W + 1) & ~1;
+    int16_t* res = reinterpret_cast<int16_t*>(lm_sm + W);
+    const int y = blockIdx.x, b = blockIdx.y;
+    const int minX1 = W - width1;
+    for (int t = 0; t < 3; t++) {
+        const int yy = min(max(y - 1 + t, 0), H - 1);
+        const int stripe = min(yy / stripe_sz, 3);
+        const int sr = si.off[stripe] + (yy - si.y0[stripe]);
+        const int32_t* w = wta + ((size_t)b * srows + sr) * W;
+        for (int x = threadIdx.x; x < W; x += 256) key[x] = 0xffffffffu;
+        __syncthreads();
+        for (int x = minX1 + threadIdx.x; x < W; x += 256) {
+            const int v = w[x];
+            const int minS = v >> 16, d16 = (short)(v & 0xffff);
+            const int bestd = (d16 + 7) >> 4;
+            if (minS != 32767)
+                atomicMin(&key[x - bestd], ((unsigned)(minS + 32768) << 16) | (unsigned)(0xffff - x));
+        }
+        __syncthreads();
+        int16_t* out = res + t * Wr;
+        for (int x = threadIdx.x; x < W; x += 256) {
+            int r = -16;
+            if (x >= minX1) {
+                const int d1 = (short)(w[x] & 0xffff);
+                const int _d = d1 >> 4, d_ = (d1 + 15) >> 4;
+                const int _x = x - _d, x_ = x - d_;
+                bool bad = true;
+                {
+                    const unsigned k = key[_x]; // 0 <= _x: a disparity is below D <= minX1 <= x
+                    const int d2 = k == 0xffffffffu ? -16 : (0xffff - (int)(k & 0xffff)) - _x;
+                    bad = bad && d2 >= 0 && abs(d2 - _d) > disp12;
+                }
+                {
+                    const bool inr = x_ >= 0;
+                    const unsigned k = inr ? key[x_] : 0xffffffffu;
+                    const int d2 = k == 0xffffffffu ? -16 : (0xffff - (int)(k & 0xffff)) - x_;
+                    bad = bad && inr && d2 >= 0 && abs(d2 - d_) > disp12;
+                }
+                r = bad ? -16 : d1;
+            }
+            out[x] = (int16_t)r;
+        }
+        __syncthreads(); // the key array is reused by the next row; res is read below
+    }
+    const size_t o0 = ((size_t)b * H + y) * W;
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const int x0 = max(x - 1, 0), x2 = min(x + 1, W - 1);
+        int p0 = res[x0], p1 = res[x], p2 = res[x2];
+        int p3 = res[Wr + x0], p4 = res[Wr + x], p5 = res[Wr + x2];
+        int p6 = res[2 * Wr + x0], p7 = res[2 * Wr + x], p8 = res[2 * Wr + x2];
+        disp_pre[o0 + x] = (int16_t)p4;
+        CSWAP(p1, p2); CSWAP(p4, p5); CSWAP(p7, p8); CSWAP(p0, p1); CSWAP(p3, p4); CSWAP(p6, p7);
+        CSWAP(p1, p2); CSWAP(p4, p5); CSWAP(p7, p8); CSWAP(p0, p3); CSWAP(p5, p8); CSWAP(p4, p7);
+        CSWAP(p3, p6); CSWAP(p1, p4); CSWAP(p2, p5); CSWAP(p4, p7); CSWAP(p4, p2); CSWAP(p6, p4);
+        CSWAP(p4, p2);
+        dst[o0 + x] = (int16_t)p4;
+        dstf[o0 + x] = (float)p4 * (1.0f / 16.0f);
+    }
 }
 
 __global__ __launch_bounds__(256) void depth_kernel(float* __restrict__ disp, size_t count, double fxb, double* __restrict__ depth)
@@ -977,11 +984,14 @@ int run_sgbm(vo_ctx* c)
                        c->stripe_sz, c->P1, c->P2, c->p.wta_simd_lanes, nseg, c->ckpt, c->wta);
     }
     { StageTimer st_(c, VO_ST_LRCHECK);
-    hipLaunchKernelGGL(lrcheck_kernel, dim3(H, n), dim3(256), (size_t)W * 4, c->stream, c->wta, W, H, w1, c->srows, si, c->stripe_sz,
-                       c->disp12, c->disp_pre);
+    const size_t lm_lds = (size_t)W * 4 + (size_t)3 * ((W + 1) & ~1) * 2;
+    static std::atomic<int> lm_attr[64];
+    if (lm_lds > 48 * 1024 && lm_attr[c->device & 63].load(std::memory_order_acquire) < (int)lm_lds) {
+        VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&lrmedian_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm_lds));
+        lm_attr[c->device & 63].store((int)lm_lds, std::memory_order_release);
     }
-    { StageTimer st_(c, VO_ST_MEDIAN);
-    hipLaunchKernelGGL(median_kernel, dim3((W + 255) / 256, H, n), dim3(256), 0, c->stream, c->disp_pre, W, H, c->disp16, c->disp32);
+    hipLaunchKernelGGL(lrmedian_kernel, dim3(H, n), dim3(256), lm_lds, c->stream, c->wta, W, H, w1, c->srows, si, c->stripe_sz,
+                       c->disp12, c->disp_pre, c->disp16, c->disp32);
     }
     VO_HIP(c, hipGetLastError());
     return VO_OK;

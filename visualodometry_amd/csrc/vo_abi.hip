@@ -161,8 +161,8 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     CR(dalloc(&c->depth, B * H * W));
     CR(dalloc(&c->score, B * H * W));
     CR(dalloc(&c->row_count, B * H));
-    CR(dalloc(&c->row_off, B * H));
-    CR(dalloc(&c->n_feat, B));
+    CR(dalloc(&c->n_feat, 3 * B)); // [3][B]: feature, match and object-point counts, fetched with one copy
+    c->n_match = c->n_feat + B; c->n_obj = c->n_feat + 2 * B;
     CR(dalloc(&c->feat, B * F));
     CR(dalloc(&c->pyr, B * 4 * c->pyr_bytes + 256)); // slack: the tracker reads 8 bytes where it needs 5
     CR(dalloc(&c->der, B * 4 * c->der_elems + 64));
@@ -170,10 +170,8 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     CR(dalloc(&c->leg_status, B * 4 * F));
     CR(dalloc(&c->m1, B * F));
     CR(dalloc(&c->m2, B * F));
-    CR(dalloc(&c->n_match, B));
     CR(dalloc(&c->obj, B * F));
     CR(dalloc(&c->obj_img, B * F));
-    CR(dalloc(&c->n_obj, B));
     CR(dalloc(&c->hyp, B * c->p.ransac_chunk * 12));
     CR(dalloc(&c->hyp_count, B * c->p.ransac_chunk));
     CR(dalloc(&c->hyp_mask, B * c->p.ransac_chunk * F));
@@ -195,8 +193,8 @@ extern "C" void vo_destroy(vo_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->img_own, c->pre, c->ring, c->cost, c->agg, c->wta, c->ckpt, c->disp_pre, c->disp16, c->disp32, c->depth, c->score,
-                    c->row_count, c->row_off, c->n_feat, c->feat, c->pyr, c->der, c->legs, c->leg_status, c->m1, c->m2, c->n_match,
-                    c->obj, c->obj_img, c->n_obj, c->hyp, c->hyp_count, c->hyp_mask};
+                    c->row_count, c->n_feat, c->feat, c->pyr, c->der, c->legs, c->leg_status, c->m1, c->m2,
+                    c->obj, c->obj_img, c->hyp, c->hyp_count, c->hyp_mask};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->cloud) (void)hipFree(c->cloud);
     if (c->cloud_rows) (void)hipFree(c->cloud_rows);
@@ -633,9 +631,7 @@ extern "C" int vo_step_submit(vo_ctx* c)
     }
     if (rc) return rc;
     if ((rc = launch_triangulate(c))) return rc;
-    VO_HIP(c, hipMemcpyAsync(c->h_counts, c->n_feat, c->n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    VO_HIP(c, hipMemcpyAsync(c->h_counts + c->p.max_batch, c->n_match, c->n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    VO_HIP(c, hipMemcpyAsync(c->h_counts + 2 * c->p.max_batch, c->n_obj, c->n * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    VO_HIP(c, hipMemcpyAsync(c->h_counts, c->n_feat, 3 * (size_t)c->p.max_batch * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (!c->step_done) VO_HIP(c, hipEventCreateWithFlags(&c->step_done, hipEventDisableTiming));
     VO_HIP(c, hipEventRecord(c->step_done, c->stream));
     c->step_pending = true;
@@ -673,7 +669,7 @@ extern "C" int vo_step(vo_ctx* c, double* Rt_out, vo_frame_info* info)
 }
 
 static const char* kStageNames[VO_NUM_STAGES] = {"sgbm_prefilter", "", "sgbm_cost_vpath", "sgbm_hpath_ckpt", "sgbm_hpath_resolve",
-    "sgbm_lrcheck", "sgbm_median", "fast", "pyramid", "lk", "klt_filter", "triangulate", "pnp_score", "pnp_host", "step_wall", ""};
+    "sgbm_lrcheck_median", "", "fast", "pyramid", "lk", "klt_filter", "triangulate", "pnp_score", "pnp_host", "step_wall", ""};
 
 extern "C" const char* vo_stage_name(int s) { return s >= 0 && s < VO_NUM_STAGES ? kStageNames[s] : ""; }
 

@@ -70,7 +70,6 @@ struct vo_ctx {
     // ---- FAST ----
     uint8_t* score = nullptr;    // [n][H][W]
     int* row_count = nullptr;    // [n][H]
-    int* row_off = nullptr;      // [n][H]
     int* n_feat = nullptr;       // [n]  (device)
     vo_point2f* feat = nullptr;  // [n][max_features]
     std::vector<int> h_nfeat;    // host copy
