@@ -8,10 +8,10 @@
 //
 //  prefilter_kernel : per pixel and image, the two Birchfield-Tomasi channels (clipped x-Sobel, raw) with
 //                     their half-pixel min/max, packed into 8 bytes.
-//  cost_vpath_kernel: 16 lanes x (D/16) disparities per cost column, 4 columns per lane group, 64 columns per block,
-//                     marching down the stripe: pixel cost, running vertical window sum, horizontal window sum
-//                     through LDS -> aggregated cost C, top-down path L_top.  The minimum over D is a DPP row
-//                     reduction; d-1 / d+1 neighbours come from DPP row shifts.
+//  cost_vpath_kernel: 16 lanes x (D/16) disparities per cost column, 4 (or 2) columns per lane group, 64 columns
+//                     per block, marching down the stripe: pixel cost from prefiltered rows staged in LDS, running
+//                     vertical window sum, horizontal window sum through LDS -> aggregated cost C, top-down path
+//                     L_top.  The minimum over D is a DPP row reduction; d-1 / d+1 neighbours come from DPP row shifts.
 //  hpath_ckpt_kernel / hpath_resolve_kernel: 16 lanes per image row, 4 rows per wavefront, serial along x.
 //                     First pass: L_lr, keeping its state at segment starts.  Second pass, right to left: L_lr of a
 //                     segment replayed into registers, L_rl, S = sum of the three paths, winner-take-all with
@@ -100,7 +100,6 @@ __global__ __launch_bounds__(256) void prefilter_kernel(const uint8_t* __restric
 // Birchfield-Tomasi cost of one channel for two adjacent disparities at once (packed 16-bit lanes).
 // u, u0, u1: the left pixel's value / half-pixel min / max, splatted.  ra, rb: the right pixels for the
 // lower and the upper disparity of the pair, bytes (v, v0, v1, -).
-__device__ __forceinline__ v2s vmax(v2s a, v2s b) { return __builtin_elementwise_max(a, b); }
 typedef unsigned short v2u __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2s sub_sat0(v2s a, v2s b)
 {
@@ -113,8 +112,9 @@ __device__ __forceinline__ v2s bt_pair(v2s u, v2s u0, v2s u1, unsigned ra, unsig
     const v2s v1 = as_v2s((int)__builtin_amdgcn_perm(rb, ra, 0x0c060c02u));
     // all operands are in [0, 255]: max(0, a - b) is an unsigned saturating subtract, and of the two one-sided
     // distances of an interval at most one is non-zero
-    const v2s c0 = vmax(sub_sat0(u, v1), sub_sat0(v0, u));
-    const v2s c1 = vmax(sub_sat0(v, u1), sub_sat0(u0, v));
+    // (so their maximum is their bitwise OR, which issues at the full rate where packed 16-bit maxima issue at half)
+    const v2s c0 = as_v2s(as_int(sub_sat0(u, v1)) | as_int(sub_sat0(v0, u)));
+    const v2s c1 = as_v2s(as_int(sub_sat0(v, u1)) | as_int(sub_sat0(u0, v)));
     return vmin(c0, c1);
 }
 
@@ -196,236 +196,25 @@ __device__ __forceinline__ void store_pk_buf(__amdgpu_buffer_rsrc_t rs, unsigned
 struct StripeInfo { int y0[4], rows[4], off[4], out0[4]; };
 
 // ---------------------------------------------------------------- pixel cost + 11x11 window + top-down path, fused
-// Block = vo_cost_threads(NP) threads in lane groups of 16; a lane group owns NCOL adjacent tile columns (CV_COLS per block,
-// SW2 of them on each side are halo), a lane 2*NP consecutive disparities of each.  Marching down the stripe:
-//   V(x, d)  = running vertical window sum of the pixel cost.  The row that enters the window is evaluated from the
-//              prefiltered rows; the row that leaves it was evaluated block_size steps earlier by the same thread and
-//              comes back from a per-thread ring of byte costs in global memory (a cost is at most 30 + 63, so 4 cells
-//              per dword; the ring has block_size + 1 slots so the slot read and the slot written always differ),
+// Block = lane groups of 16; a lane group owns NCOL adjacent tile columns (64 per block, SW2 of them on each side are
+// halo), a lane 2*NP consecutive disparities of each.  Marching down the stripe:
+//   V(x, d)  = running vertical window sum of the pixel cost: the row that enters the window is evaluated and added, the
+//              row that leaves it is evaluated AGAIN and subtracted.  No per-thread history of evaluated rows exists,
+//              neither in registers nor in LDS nor in memory: keeping one (a ring of byte costs) made the kernel
+//              write-bound at KITTI shape and cost the wide disparity ranges their occupancy;
 //   C(x, d)  = horizontal window sum of V through LDS (sliding over the group's columns),
 //   L_top    = one path step per column; C and L_top are the only HBM traffic (one write each).
-
-// SWC: the half window as a compile-time constant (0 = use the run-time SW2; slower horizontal sum)
-// NCOL: tile columns per lane group (4; 2 for wide disparity ranges, where 4 columns x 2NP cells do not fit the registers)
-template <int NP, int SWC, int NCOL>
-__global__ __launch_bounds__(vo_cost_threads(NP)) void cost_vpath_kernel(const uint2* __restrict__ pre, int W, int H, int Wp, int width1, int D, int SW2,
-                                                         int srows, StripeInfo si, int P1, int P2, int16_t* __restrict__ cost,
-                                                         int16_t* __restrict__ agg, uint32_t* __restrict__ ring, int lds_slots)
-{
-    constexpr int VO_COST_THREADS = vo_cost_threads(NP);
-    constexpr int CV_COLS = (VO_COST_THREADS / 16) * NCOL;
-    extern __shared__ int vt[]; // [2][CV_COLS][CS]: V of every tile column, dword (k, lane16) at k*16 + lane16
-    constexpr int CS = 16 * NP + 4;
-    constexpr int NR = 2 * NP + NCOL - 1;
-    const int lane16 = threadIdx.x & 15, q = threadIdx.x >> 4;
-    const int stripe = blockIdx.y, b = blockIdx.z;
-    const int y0 = si.y0[stripe], rows = si.rows[stripe];
-    if (rows <= 0) return;
-    const int tile_out = CV_COLS - 2 * SW2;
-    const int xc0 = blockIdx.x * tile_out - SW2; // cost column of tile column 0
-    const int minX1 = W - width1;
-    const int cb = q * NCOL;
-    const int d0 = lane16 * 2 * NP;
-    const uint2* Lb = pre + ((size_t)b * 2 + 0) * H * Wp;
-    const uint2* Rb = pre + ((size_t)b * 2 + 1) * H * Wp;
-    unsigned xl[NCOL]; // byte offsets into the frame's prefiltered image: buffer lane offsets
-#pragma unroll
-    for (int j = 0; j < NCOL; j++) xl[j] = 8u * (unsigned)(minX1 + min(max(xc0 + cb + j, 0), width1 - 1));
-    // right pixel of (column j, slot s) is r[j - s + 2NP - 1] with r[i] = R[xr0 + i]
-    const int xr0 = minX1 + xc0 + cb - d0 - (2 * NP - 1);
-    unsigned xr[NR];
-#pragma unroll
-    for (int i = 0; i < NR; i++) xr[i] = 8u * (unsigned)min(max(xr0 + i, 0), W - 1);
-
-    const unsigned img_bytes = (unsigned)H * (unsigned)Wp * 8u;
-    const __amdgpu_buffer_rsrc_t Lrs = make_rsrc(Lb, img_bytes), Rrs = make_rsrc(Rb, img_bytes);
-    auto pix_row = [&](int row, v2s (&out)[NCOL][NP]) {
-        const int so = row * Wp * 8; // uniform
-        v2u32 r[NR];
-#pragma unroll
-        for (int i = 0; i < NR; i++) r[i] = __builtin_amdgcn_raw_buffer_load_b64(Rrs, (int)xr[i], so, 0);
-#pragma unroll
-        for (int j = 0; j < NCOL; j++) {
-            const v2u32 l = __builtin_amdgcn_raw_buffer_load_b64(Lrs, (int)xl[j], so, 0);
-            const v2s g = splat(l.x & 0xff), g0 = splat((l.x >> 8) & 0xff), g1 = splat((l.x >> 16) & 0xff);
-            const v2s w = splat(l.y & 0xff), w0 = splat((l.y >> 8) & 0xff), w1 = splat((l.y >> 16) & 0xff);
-#pragma unroll
-            for (int k = 0; k < NP; k++) {
-                const int ia = j - 2 * k + 2 * NP - 1; // slot 2k (lower d); slot 2k+1 is ia - 1
-                out[j][k] = bt_pair(g, g0, g1, r[ia].x, r[ia - 1].x) + (bt_pair(w, w0, w1, r[ia].y, r[ia - 1].y) >> 2);
-            }
-        }
-    };
-
-    // ring of evaluated rows: slot s, dword w of thread tid at ((blk * nslot + s) * RW + w) * VO_COST_THREADS + tid
-    const int nslot = 2 * SW2 + 2;
-    constexpr int RW = NCOL * NP / 2; // ring dwords per thread and slot: 4 byte costs each
-    static_assert((NCOL * NP) % 2 == 0, "the ring packs pairs of pairs");
-    uint32_t* rg = ring + ((size_t)((b * 4 + stripe) * gridDim.x + blockIdx.x) * nslot) * (RW * VO_COST_THREADS); // uniform
-    const unsigned tid = threadIdx.x;
-    // the first lds_slots slots of the ring live in what LDS the tile leaves free (same layout; a thread only ever
-    // reads back its own dwords, so no barrier is involved); the others in global memory
-    typedef __attribute__((address_space(3))) unsigned lds_u32;
-    lds_u32* lring = (lds_u32*)(vt + 2 * CV_COLS * CS);
-    const __amdgpu_buffer_rsrc_t grs = make_rsrc(rg, (unsigned)(nslot * RW * VO_COST_THREADS * 4));
-    auto ring_put = [&](int slot, const v2s (&src)[NCOL][NP]) {
-        unsigned pk[RW];
-#pragma unroll
-        for (int w = 0; w < RW; w++) { // cells (2w, 2w+1) of the thread's NCOL x NP pairs, low bytes
-            const int a0 = 2 * w, a1 = 2 * w + 1;
-            pk[w] = __builtin_amdgcn_perm((unsigned)as_int(src[a1 / NP][a1 % NP]), (unsigned)as_int(src[a0 / NP][a0 % NP]), 0x06040200u);
-        }
-        if (slot < lds_slots) {
-            lds_u32* q_ = lring + slot * (RW * VO_COST_THREADS);
-#pragma unroll
-            for (int w = 0; w < RW; w++) q_[w * VO_COST_THREADS + tid] = pk[w];
-        } else {
-#pragma unroll
-            for (int w = 0; w < RW; w++)
-                __builtin_amdgcn_raw_buffer_store_b32(pk[w], grs, (int)(tid * 4 + w * (VO_COST_THREADS * 4)), slot * (RW * VO_COST_THREADS * 4), 0);
-        }
-    };
-    auto ring_get = [&](int slot, v2s (&dst)[NCOL][NP]) {
-        unsigned pk[RW];
-        if (slot < lds_slots) {
-            const lds_u32* q_ = lring + slot * (RW * VO_COST_THREADS);
-#pragma unroll
-            for (int w = 0; w < RW; w++) pk[w] = q_[w * VO_COST_THREADS + tid];
-        } else {
-#pragma unroll
-            for (int w = 0; w < RW; w++)
-                pk[w] = __builtin_amdgcn_raw_buffer_load_b32(grs, (int)(tid * 4 + w * (VO_COST_THREADS * 4)), slot * (RW * VO_COST_THREADS * 4), 0);
-        }
-#pragma unroll
-        for (int w = 0; w < RW; w++) {
-            const int a0 = 2 * w, a1 = 2 * w + 1;
-            dst[a0 / NP][a0 % NP] = as_v2s((int)__builtin_amdgcn_perm(0u, pk[w], 0x0c010c00u));
-            dst[a1 / NP][a1 % NP] = as_v2s((int)__builtin_amdgcn_perm(0u, pk[w], 0x0c030c02u));
-        }
-    };
-
-    // window rows are numbered relative to the stripe top; rows above it repeat row 0.  Row q lives in slot (q + nslot) % nslot.
-    v2s V[NCOL][NP], t[NCOL][NP], Lp[NCOL][NP];
-    int m[NCOL];
-#pragma unroll
-    for (int j = 0; j < NCOL; j++) m[j] = 0;
-    pix_row(y0, t);
-#pragma unroll
-    for (int j = 0; j < NCOL; j++)
-#pragma unroll
-        for (int k = 0; k < NP; k++) { V[j][k] = t[j][k] * (short)(SW2 + 1); Lp[j][k] = splat(0); }
-    for (int q = -SW2; q <= 0; q++) ring_put((q + nslot) % nslot, t);
-    for (int dy = 1; dy <= SW2; dy++) {
-        if (y0 + dy <= H - 1) pix_row(y0 + dy, t); // past the last image row the last row repeats: t already holds it
-        ring_put(dy, t);
-#pragma unroll
-        for (int j = 0; j < NCOL; j++)
-#pragma unroll
-            for (int k = 0; k < NP; k++) V[j][k] += t[j][k];
-    }
-    const int inf_pk = (32767 - P1) * 0x10001;
-    // tile columns that hold the first / last cost column: the horizontal window clamps there
-    const int cmin = max(-xc0, 0), cmax = min(width1 - 1 - xc0, CV_COLS - 1);
-    constexpr int NC = NCOL + 2 * (SWC > 0 ? SWC : 1);
-    int cidx[NC];
-#pragma unroll
-    for (int i = 0; i < NC; i++) cidx[i] = min(max(cb - SWC + i, cmin), cmax) * CS + lane16;
-    const size_t rstride = (size_t)width1 * D;
-    // output addressing: a buffer per row + a 32-bit byte offset per owned column (VO_BUF_SKIP = not stored: halo or past the row)
-    const unsigned row_bytes = (unsigned)(rstride * sizeof(int16_t));
-    char* crow = reinterpret_cast<char*>(cost + ((size_t)b * srows + si.off[stripe]) * rstride);
-    char* arow = reinterpret_cast<char*>(agg + ((size_t)b * srows + si.off[stripe]) * rstride);
-    unsigned ocol[NCOL];
-#pragma unroll
-    for (int j = 0; j < NCOL; j++) {
-        const int c = cb + j, xc = xc0 + c;
-        ocol[j] = (c >= SW2 && c < CV_COLS - SW2 && xc < width1) ? (unsigned)((xc * D + d0) * (int)sizeof(int16_t)) : VO_BUF_SKIP;
-    }
-
-    for (int r = 0; r < rows; r++) {
-        const int y = y0 + r;
-        if (r > 0) {
-            v2s gone[NCOL][NP];
-            ring_get((r - SW2 - 1 + nslot) % nslot, gone);      // row r - SW2 - 1 leaves the window
-            if (y + SW2 <= H - 1) pix_row(y + SW2, t);          // row r + SW2 enters it (the last image row repeats)
-            ring_put((r + SW2) % nslot, t);
-#pragma unroll
-            for (int j = 0; j < NCOL; j++)
-#pragma unroll
-                for (int k = 0; k < NP; k++) V[j][k] += t[j][k] - gone[j][k];
-        }
-        int* buf = vt + (r & 1) * (CV_COLS * CS);
-#pragma unroll
-        for (int j = 0; j < NCOL; j++)
-#pragma unroll
-            for (int k = 0; k < NP; k++) buf[(cb + j) * CS + k * 16 + lane16] = as_int(V[j][k]);
-        __syncthreads(); // one barrier per row: the other buffer is rewritten only after the next barrier
-        v2s C[NCOL][NP];
-        if (SWC > 0) {
-            // compile-time window: the group's NCOL windows span NCOL + 2*SWC columns; every column is read once, at an
-            // LDS offset that does not depend on the row (clamped at the ends of the cost row)
-            v2s col[NC][NP];
-#pragma unroll
-            for (int i = 0; i < NC; i++) {
-                const int* p = buf + cidx[i];
-#pragma unroll
-                for (int k = 0; k < NP; k++) col[i][k] = as_v2s(p[k * 16]);
-            }
-#pragma unroll
-            for (int k = 0; k < NP; k++) {
-                v2s a = col[0][k];
-#pragma unroll
-                for (int i = 1; i <= 2 * SWC; i++) a += col[i][k];
-                C[0][k] = a;
-#pragma unroll
-                for (int j = 1; j < NCOL; j++) C[j][k] = C[j - 1][k] + col[j + 2 * SWC][k] - col[j - 1][k];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < NP; k++) C[0][k] = splat(0);
-            for (int dx = -SW2; dx <= SW2; dx++) {
-                const int* p = buf + min(max(cb + dx, cmin), cmax) * CS + lane16;
-#pragma unroll
-                for (int k = 0; k < NP; k++) C[0][k] += as_v2s(p[k * 16]);
-            }
-#pragma unroll
-            for (int j = 1; j < NCOL; j++) {
-                const int* pa = buf + min(max(cb + j + SW2, cmin), cmax) * CS + lane16;
-                const int* ps = buf + min(max(cb + j - 1 - SW2, cmin), cmax) * CS + lane16;
-#pragma unroll
-                for (int k = 0; k < NP; k++) C[j][k] = C[j - 1][k] + as_v2s(pa[k * 16]) - as_v2s(ps[k * 16]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NCOL; j++) m[j] = path_step<NP>(C[j], Lp[j], m[j], P1, P2, inf_pk); // independent chains
-        if (y >= si.out0[stripe]) { // warm-up rows only feed the vertical path's state: nothing reads their C or L_top
-            const __amdgpu_buffer_rsrc_t crs = make_rsrc(crow, row_bytes), ars = make_rsrc(arow, row_bytes);
-#pragma unroll
-            for (int j = 0; j < NCOL; j++) {
-                store_pk_buf<NP>(crs, ocol[j], C[j]);
-                store_pk_buf<NP>(ars, ocol[j], Lp[j]);
-            }
-        }
-        crow += rstride * sizeof(int16_t); arow += rstride * sizeof(int16_t);
-    }
-}
-
-// ---------------------------------------------------------------- the same for wide disparity ranges (160 .. 256)
-// With 10 .. 16 cells per lane and column the kernel above needs ~200 registers, which leaves one 512-thread block per CU:
-// two wavefronts per SIMD, all in one barrier domain, cannot hide the per-row barrier and the memory latency.  This form
-// is written for 128 registers, so that two blocks (four wavefronts per SIMD) share a CU:
-//   - no ring: the row that leaves the vertical window is evaluated again and subtracted, so no per-thread row history
-//     exists, neither in registers nor in LDS nor in memory;
+// The kernel is written for 128 registers (four wavefronts per SIMD: four 256-thread blocks, or two 512-thread blocks for
+// 160 disparities and more, where a lane group takes 2 columns instead of 4):
 //   - the prefiltered pixels a tile needs for one image row (64 left, D + 64 right) are staged in LDS by the whole block,
 //     one row ahead: a thread requests its two pixels at the top of a row and stores them to LDS at the bottom, so the
-//     memory latency hides behind the row's arithmetic, and every lane then reads its 2NP + 1 right pixels from LDS
+//     memory latency hides behind the row's arithmetic, and every lane then reads its 2NP + NCOL - 1 right pixels from LDS
 //     (one pad slot per 16 pixels keeps the lanes of a group, 2NP pixels apart, on different banks);
-//   - every evaluated cost goes straight into the running sum V (one packed multiply-add), nothing is kept per row;
+//   - every evaluated cost goes straight into the running sum V, nothing is kept per row;
 //   - the horizontal window is summed one register column (k) at a time.
-template <int NP>
-struct WideTile {
-    static constexpr int NCOL = 2, THREADS = 512;
-    static constexpr int CV_COLS = (THREADS / 16) * NCOL;  // 64
+template <int NP, int NCOL_>
+struct CostTile {
+    static constexpr int NCOL = NCOL_, CV_COLS = 64, THREADS = (CV_COLS / NCOL) * 16; // 512 threads at 2 columns per lane group, 256 at 4
     static constexpr int CS = 16 * NP + 4;                  // dwords per tile column of V
     static constexpr int RPX = CV_COLS + 32 * NP;           // right pixels per tile and row: x0 - D .. x0 + 63
     static constexpr int RSLOTS = RPX + RPX / 16;           // with the pad slots
@@ -434,12 +223,12 @@ struct WideTile {
     static constexpr size_t lds_bytes() { return (size_t)2 * CV_COLS * CS * 4 + (size_t)2 * 2 * EVAL_SLOTS * 8; }
 };
 
-template <int NP, int SWC>
-__global__ __launch_bounds__(512, 4) void cost_vpath_wide_kernel(const uint2* __restrict__ pre, int W, int H, int Wp, int width1, int D, int SW2,
+template <int NP, int SWC, int NCOL_>
+__global__ __launch_bounds__((CostTile<NP, NCOL_>::THREADS), 4) void cost_vpath_kernel(const uint2* __restrict__ pre, int W, int H, int Wp, int width1, int D, int SW2,
                                                                  int srows, StripeInfo si, int P1, int P2, int16_t* __restrict__ cost,
                                                                  int16_t* __restrict__ agg)
 {
-    typedef WideTile<NP> T;
+    typedef CostTile<NP, NCOL_> T;
     constexpr int NCOL = T::NCOL, CV_COLS = T::CV_COLS, CS = T::CS;
     constexpr int NR = 2 * NP + NCOL - 1;
     extern __shared__ int vt[];                    // [2][CV_COLS][CS] V tiles, then [2][2][EVAL_SLOTS] staged pixels (8 bytes each)
@@ -486,8 +275,8 @@ __global__ __launch_bounds__(512, 4) void cost_vpath_wide_kernel(const uint2* __
 
     v2s V[NCOL][NP], Lp[NCOL][NP];
     // A row evaluation runs in two halves of the lane's disparity pairs, upper half first: pairs k >= KH need the lane's
-    // right pixels 0 .. MID, pairs k < KH the pixels MID .. 2NP, so only half of them are in registers at a time.
-    constexpr int KH = NP / 2, MID = 2 * (NP - KH);
+    // right pixels 0 .. MID, pairs k < KH the pixels 2 (NP - KH) .. NR - 1, so only about half of them are in registers at a time.
+    constexpr int KH = NP / 2, MID = 2 * (NP - KH) + NCOL - 2;
     auto add_cost = [&](const v2u32 (&r)[NR], const v2u32 (&l)[NCOL], int scale, int k_begin, int k_end) {
         const v2s sc = splat(scale);
 #pragma unroll
@@ -914,58 +703,26 @@ int run_sgbm(vo_ctx* c)
     { StageTimer st_(c, VO_ST_VPATH);
     // the reference's window (11x11, Source/VOClass.cpp:242) gets the instantiation with a compile-time half window
     const int swc = SH2 == 5 ? 5 : 0;
-    if constexpr (NP >= VO_COST_WIDE_NP) {
-        // wide disparity ranges: the 128-register form without a ring, two 512-thread blocks per CU
-        constexpr int TILE_COLS = WideTile<NP>::CV_COLS;
-        const size_t lds = WideTile<NP>::lds_bytes();
-        const void* fn = swc ? reinterpret_cast<const void*>(&cost_vpath_wide_kernel<NP, 5>) : reinterpret_cast<const void*>(&cost_vpath_wide_kernel<NP, 0>);
+    {
+        // 2 columns per lane group (512-thread blocks) for the wide disparity ranges, 4 (256-thread blocks) below
+        constexpr int WN = NP >= 5 ? 2 : 4;
+        typedef CostTile<NP, WN> WT;
+        constexpr int TILE_COLS = WT::CV_COLS;
+        const size_t lds = WT::lds_bytes();
+        const void* fn = swc ? reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 5, WN>) : reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 0, WN>);
         static std::atomic<int> wide_attr[64][2];
         if (lds > 48 * 1024 && wide_attr[c->device & 63][swc ? 1 : 0].load(std::memory_order_acquire) < (int)lds) {
             VO_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             wide_attr[c->device & 63][swc ? 1 : 0].store((int)lds, std::memory_order_release);
         }
         const int tile_out = TILE_COLS - 2 * SH2;
-        const dim3 grid((w1 + tile_out - 1) / tile_out, 4, n), blk(512);
+        const dim3 grid((w1 + tile_out - 1) / tile_out, 4, n), blk(WT::THREADS);
         if (swc)
-            hipLaunchKernelGGL((cost_vpath_wide_kernel<NP, 5>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
+            hipLaunchKernelGGL((cost_vpath_kernel<NP, 5, WN>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
                                SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg);
         else
-            hipLaunchKernelGGL((cost_vpath_wide_kernel<NP, 0>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
+            hipLaunchKernelGGL((cost_vpath_kernel<NP, 0, WN>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
                                SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg);
-    } else {
-        constexpr int NCOL = vo_cost_group_cols(NP);
-        constexpr int VO_COST_THREADS = vo_cost_threads(NP);
-        constexpr int TILE_COLS = (VO_COST_THREADS / 16) * NCOL;
-        // LDS: the double-buffered tile, plus as many ring slots as fit a third of a CU's 160 KB (three blocks per CU
-        // is what the kernel's register use allows at 96 disparities); the 512-thread blocks of the wide disparity ranges
-        // are alone on their CU (two wavefronts per SIMD at ~200 registers) and take nearly all of it
-    #ifndef VO_COST_LDS_BUDGET
-    #define VO_COST_LDS_BUDGET (52 * 1024)
-    #endif
-        const size_t lds_budget = VO_COST_THREADS > 256 ? (size_t)150 * 1024 : (size_t)VO_COST_LDS_BUDGET;
-        const size_t tile_bytes = (size_t)2 * TILE_COLS * (16 * NP + 4) * sizeof(int);
-        const size_t slot_bytes = (size_t)(NCOL * NP / 2) * VO_COST_THREADS * sizeof(unsigned);
-        const int lds_slots = tile_bytes >= lds_budget ? 0
-                            : (int)std::min<size_t>((lds_budget - tile_bytes) / slot_bytes, (size_t)(2 * SH2 + 2));
-        const size_t lds = tile_bytes + lds_slots * slot_bytes;
-        const void* fn = swc ? reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 5, NCOL>) : reinterpret_cast<const void*>(&cost_vpath_kernel<NP, 0, NCOL>);
-        // The dynamic-LDS ceiling of a kernel belongs to the device's copy of the code object and must cover every launch:
-        // `lds` varies with block_size (the ring slots are capped at block_size + 1), so the attribute is set to the budget
-        // itself (or the tile, if that alone exceeds it), which bounds `lds` for this instantiation, and raised if ever needed.
-        static std::atomic<int> lds_attr[64][2];
-        const int lds_cap = (int)std::max(lds_budget, tile_bytes);
-        if (lds > 48 * 1024 && lds_attr[c->device & 63][swc ? 1 : 0].load(std::memory_order_acquire) < lds_cap) {
-            VO_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_cap));
-            lds_attr[c->device & 63][swc ? 1 : 0].store(lds_cap, std::memory_order_release);
-        }
-        const int tile_out = TILE_COLS - 2 * SH2;
-        const dim3 grid((w1 + tile_out - 1) / tile_out, 4, n), blk(VO_COST_THREADS);
-        if (swc)
-            hipLaunchKernelGGL((cost_vpath_kernel<NP, 5, NCOL>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
-                               SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring, lds_slots);
-        else
-            hipLaunchKernelGGL((cost_vpath_kernel<NP, 0, NCOL>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
-                               SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->ring, lds_slots);
     }
     }
     const int nseg = vo_hpath_segments(c);

@@ -150,7 +150,6 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     c->own_pitch = (W + 63) & ~(size_t)63; c->own_fstride = c->own_pitch * H;
     CR(dalloc(&c->img_own, 4 * B * c->own_fstride));
     CR(dalloc(&c->pre, B * 2 * H * (size_t)vo_pre_pitch(c) * 8 + 4096)); // slack: the wide cost kernel reads a few columns past the last row of halo tiles
-    CR(dalloc(&c->ring, B * 4 * vo_cost_tiles(c) * (c->p.block_size + 1) * vo_cost_ring_dwords(c) * vo_cost_threads(c->D / 32)));
     CR(dalloc(&c->cost, B * c->srows * w1 * D));
     CR(dalloc(&c->agg, B * c->srows * w1 * D));
     CR(dalloc(&c->wta, B * c->srows * W));
@@ -192,7 +191,7 @@ extern "C" void vo_destroy(vo_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = {c->img_own, c->pre, c->ring, c->cost, c->agg, c->wta, c->ckpt, c->disp_pre, c->disp16, c->disp32, c->depth, c->score,
+    void* bufs[] = {c->img_own, c->pre, c->cost, c->agg, c->wta, c->ckpt, c->disp_pre, c->disp16, c->disp32, c->depth, c->score,
                     c->row_count, c->n_feat, c->feat, c->pyr, c->der, c->legs, c->leg_status, c->m1, c->m2,
                     c->obj, c->obj_img, c->hyp, c->hyp_count, c->hyp_mask};
     for (void* b : bufs) if (b) (void)hipFree(b);

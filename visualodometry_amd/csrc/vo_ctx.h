@@ -56,7 +56,6 @@ struct vo_ctx {
 
     // ---- SGBM ----
     uint8_t* pre = nullptr;      // prefiltered rows: [n][2 images][H][vo_pre_pitch] x 8 bytes (g,g0,g1,0,r,r0,r1,0)
-    uint32_t* ring = nullptr;    // pixel-cost rows in flight of the cost kernel: [n][4 stripes][x tiles][block_size + 1][D / 16][256]
     int16_t* cost = nullptr;     // [n][srows][width1][D]
     int16_t* agg = nullptr;      // [n][srows][width1][D]  L_top, then L_top + L_lr
     int32_t* wta = nullptr;      // [n][srows][W] packed (minS << 16) | (d16 & 0xffff)
@@ -129,25 +128,12 @@ int vo_fail(vo_ctx* c, int code, const char* fmt, ...);
         if (e__ != hipSuccess) return vo_fail((c), VO_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
     } while (0)
 
-// cost kernel tiling: a block of vo_cost_threads() threads in lane groups of 16; a group owns vo_cost_group_cols() adjacent
-// cost columns (4; 2 once a lane holds 12 or more disparities of each, and then twice the threads, so that a tile stays
-// 64 columns wide); block_size / 2 columns on each side of the tile are halo
-#ifndef VO_COST_WIDE_THREADS
-#define VO_COST_WIDE_THREADS 512
-#endif
-// from this many disparity pairs per lane on (160 disparities), the cost kernel is the ring-less wide form (sgbm.hip)
-#ifndef VO_COST_WIDE_NP
-#define VO_COST_WIDE_NP 5
-#endif
-constexpr int vo_cost_group_cols(int pairs_per_lane) { return pairs_per_lane >= 6 ? 2 : 4; }
-constexpr int vo_cost_threads(int pairs_per_lane) { return pairs_per_lane >= 6 ? VO_COST_WIDE_THREADS : 256; }
+// cost kernel tiling: 64 tile columns per block, block_size / 2 of them on each side are halo
 inline size_t vo_cost_tiles(const vo_ctx* c)
 {
-    const int tile_out = (vo_cost_threads(c->D / 32) / 16) * vo_cost_group_cols(c->D / 32) - 2 * (c->p.block_size / 2);
+    const int tile_out = 64 - 2 * (c->p.block_size / 2);
     return (size_t)((c->width1 + tile_out - 1) / tile_out);
 }
-// dwords of the pixel-cost ring per thread and slot (4 byte costs per dword)
-inline size_t vo_cost_ring_dwords(const vo_ctx* c) { return c->D / 32 >= VO_COST_WIDE_NP ? 0 : (size_t)vo_cost_group_cols(c->D / 32) * (c->D / 32) / 2; }
 
 // horizontal paths: the left-to-right state is checkpointed every segment; a segment's columns live in registers,
 // so wide disparity ranges (more cells per lane) get shorter segments
