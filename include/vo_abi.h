@@ -56,7 +56,7 @@ typedef struct {
     int max_features;         /* capacity per image; FAST output beyond it is truncated (row-major order) */
     /* StereoSGBM, MODE_SGBM_3WAY */
     int min_disparity;        /* 0 (only 0 is supported) */
-    int num_disparities;      /* 96; multiple of 32 in [32, 256] (OpenCV itself takes any multiple of 16) */
+    int num_disparities;      /* 96; multiple of 16 in [16, 256] */
     int block_size;           /* 11; odd, <= 13 (aggregated cost must fit 14 bits) */
     int p1, p2;               /* 968, 3872 */
     int disp12_max_diff;      /* 0 -> 1 */

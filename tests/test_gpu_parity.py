@@ -339,7 +339,7 @@ def test_edge_cases(small_seq):
     assert np.array_equal(small.features(), ob.fast(imgs[0])[:64])
     # bad arguments
     with pytest.raises(abi.VoError):
-        make_ctx(SMALL_W, SMALL_H, num_disparities=48)
+        make_ctx(SMALL_W, SMALL_H, num_disparities=40)
     with pytest.raises(ValueError):
         ctx.set_images(flat[:10], flat, flat, flat)
 

@@ -19,6 +19,13 @@ CONFIGS = [
     (417, 57, 192, 7, 15, 16),
     (390, 46, 224, 11, 3, 8),
     (450, 43, 256, 5, 15, 8),
+    # ranges that are a multiple of 16 but not of 32
+    (120, 49, 16, 7, 9, 8),
+    (211, 53, 48, 11, 15, 8),
+    (275, 47, 80, 5, 15, 16),
+    (305, 58, 112, 9, 21, 0),
+    (380, 45, 176, 3, 15, 8),
+    (470, 41, 240, 11, 15, 8),
 ]
 
 
@@ -45,6 +52,8 @@ def test_stages_against_oracle(cfg):
     assert np.array_equal(ctx.tap(abi.TAP_DISP_PREMEDIAN), want_pre)
     assert np.array_equal(ctx.disparity16(0), want)
     assert np.array_equal(ctx.disparity32(0), ob.disp_to_float(want))
+    # one aggregated cost row (width1 x D, whatever stride the library keeps it at)
+    assert np.array_equal(ctx.tap(abi.TAP_COST_ROW, 0, 0, 3), ob.sgbm_cost_row(imgs[0], imgs[1], op, 0, 3))
 
     # FAST: same keypoints in the same order
     ctx.detect_fast()

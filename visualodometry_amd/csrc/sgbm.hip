@@ -226,7 +226,7 @@ struct CostTile {
 template <int NP, int SWC, int NCOL_>
 __global__ __launch_bounds__((CostTile<NP, NCOL_>::THREADS), 4) void cost_vpath_kernel(const uint2* __restrict__ pre, int W, int H, int Wp, int width1, int D, int SW2,
                                                                  int srows, StripeInfo si, int P1, int P2, int16_t* __restrict__ cost,
-                                                                 int16_t* __restrict__ agg)
+                                                                 int16_t* __restrict__ agg, int live_d, int dead_cost)
 {
     typedef CostTile<NP, NCOL_> T;
     constexpr int NCOL = T::NCOL, CV_COLS = T::CV_COLS, CS = T::CS;
@@ -414,6 +414,13 @@ __global__ __launch_bounds__((CostTile<NP, NCOL_>::THREADS), 4) void cost_vpath_
                 for (int k = 0; k < NP; k++) C[j][k] = C[j - 1][k] + as_v2s(pa[k * 16]) - as_v2s(ps[k * 16]);
             }
         }
+        if (live_d < D) { // a padded disparity range: the cells beyond it get the cost no path prefers (uniform branch)
+            const v2s dead = splat(dead_cost);
+#pragma unroll
+            for (int j = 0; j < NCOL; j++)
+#pragma unroll
+                for (int k = 0; k < NP; k++) C[j][k] = d0 + 2 * k >= live_d ? dead : C[j][k];
+        }
 #pragma unroll
         for (int j = 0; j < NCOL; j++) m[j] = path_step<NP>(C[j], Lp[j], m[j], P1, P2, inf_pk);
         if (y >= si.out0[stripe]) {
@@ -492,9 +499,10 @@ __global__ __launch_bounds__(256) void hpath_ckpt_kernel(const int16_t* __restri
 
 template <int NP>
 __global__ __launch_bounds__(64) void hpath_resolve_kernel(const int16_t* __restrict__ cost, const int16_t* __restrict__ ltop, int width1,
-                                                            int D, int W, int H, int srows, StripeInfo si, int stripe_sz, int P1, int P2,
-                                                            int tie_lanes, int nseg, const int* __restrict__ ckpt, int32_t* __restrict__ wta)
+                                                            int Dp, int W, int H, int srows, StripeInfo si, int stripe_sz, int P1, int P2,
+                                                            int tie_lanes, int nseg, const int* __restrict__ ckpt, int32_t* __restrict__ wta, int D)
 {
+    // Dp: disparity stride of the volumes (a multiple of 32, what NP is instantiated for); D: the disparity range searched
     constexpr int HP_SEG = vo_hpath_seg(NP);
     const int lane16 = threadIdx.x & 15;
     const int y = blockIdx.x * 4 + (threadIdx.x >> 4); // one wavefront per block: four rows
@@ -502,7 +510,7 @@ __global__ __launch_bounds__(64) void hpath_resolve_kernel(const int16_t* __rest
     const bool active = y < H;
     const int yy = active ? y : H - 1;
     const int sr = stripe_row_of(si, stripe_sz, yy);
-    const size_t base = (((size_t)b * srows + sr) * width1) * D + lane16 * (2 * NP);
+    const size_t base = (((size_t)b * srows + sr) * width1) * Dp + lane16 * (2 * NP);
     const int16_t* Cp = cost + base;
     const int16_t* Tp = ltop + base;
     const int* ck = ckpt + (((size_t)b * H + yy) * nseg * 16 + lane16) * (NP + 1);
@@ -523,7 +531,7 @@ __global__ __launch_bounds__(64) void hpath_resolve_kernel(const int16_t* __rest
     auto load_cols = [&](const int16_t* p, int s, v2s (&g)[HP_SEG][NP], int u0, int u1) {
 #pragma unroll
         for (int u = 0; u < HP_SEG; u++)
-            if (u >= u0 && u < u1) load_pk<NP>(p + (size_t)min(s * HP_SEG + u, width1 - 1) * D, g[u]);
+            if (u >= u0 && u < u1) load_pk<NP>(p + (size_t)min(s * HP_SEG + u, width1 - 1) * Dp, g[u]);
     };
     auto load_seg = [&](const int16_t* p, int s, v2s (&g)[HP_SEG][NP]) { load_cols(p, s, g, 0, HP_SEG); };
     auto load_ck = [&](int s, int (&c)[NP + 1]) {
@@ -557,7 +565,11 @@ __global__ __launch_bounds__(64) void hpath_resolve_kernel(const int16_t* __rest
             if (u < cols) { // uniform
                 mR = path_step<NP>(Cc[u], LpR, mR, P1, P2, inf_pk);
 #pragma unroll
-                for (int k = 0; k < NP; k++) trow[u * STR + lane16 * NP + k] = as_int(__builtin_elementwise_add_sat(LpR[k], Lrec[u][k] + Tt[u][k]));
+                for (int k = 0; k < NP; k++) {
+                    const int sum = as_int(__builtin_elementwise_add_sat(LpR[k], Lrec[u][k] + Tt[u][k]));
+                    // cells of a padded range can never win (their inner sum may have wrapped: it is not looked at)
+                    trow[u * STR + lane16 * NP + k] = lane16 * 2 * NP + 2 * k >= D ? 0x7fff7fff : sum;
+                }
             }
         }
         if (s > 0) load_cols(Cp, s - 1, Cn, HP_SEG / 2, HP_SEG);
@@ -692,7 +704,7 @@ __global__ __launch_bounds__(256) void depth_kernel(float* __restrict__ disp, si
 template <int NP>
 int run_sgbm(vo_ctx* c)
 {
-    const int W = c->W, H = c->H, D = c->D, w1 = c->width1, n = c->n, SH2 = c->p.block_size / 2;
+    const int W = c->W, H = c->H, D = c->Dp, w1 = c->width1, n = c->n, SH2 = c->p.block_size / 2; // D: the padded range (volume stride)
     const int Wp = vo_pre_pitch(c);
     StripeInfo si;
     for (int s = 0; s < 4; s++) { si.y0[s] = c->stripe_y0[s]; si.rows[s] = c->stripe_rows[s]; si.off[s] = c->stripe_row_off[s]; si.out0[s] = std::min(s * c->stripe_sz, H); }
@@ -719,10 +731,10 @@ int run_sgbm(vo_ctx* c)
         const dim3 grid((w1 + tile_out - 1) / tile_out, 4, n), blk(WT::THREADS);
         if (swc)
             hipLaunchKernelGGL((cost_vpath_kernel<NP, 5, WN>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
-                               SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg);
+                               SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->D, c->dead_cost);
         else
             hipLaunchKernelGGL((cost_vpath_kernel<NP, 0, WN>), grid, blk, lds, c->stream, reinterpret_cast<const uint2*>(c->pre), W, H, Wp, w1, D,
-                               SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg);
+                               SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->D, c->dead_cost);
     }
     }
     const int nseg = vo_hpath_segments(c);
@@ -738,7 +750,7 @@ int run_sgbm(vo_ctx* c)
         hp_attr[c->device & 63].store((int)hp_lds, std::memory_order_release);
     }
     hipLaunchKernelGGL((hpath_resolve_kernel<NP>), dim3((H + 3) / 4, n), dim3(64), hp_lds, c->stream, c->cost, c->agg, w1, D, W, H, c->srows, si,
-                       c->stripe_sz, c->P1, c->P2, c->p.wta_simd_lanes, nseg, c->ckpt, c->wta);
+                       c->stripe_sz, c->P1, c->P2, c->p.wta_simd_lanes, nseg, c->ckpt, c->wta, c->D);
     }
     { StageTimer st_(c, VO_ST_LRCHECK);
     const size_t lm_lds = (size_t)W * 4 + (size_t)3 * ((W + 1) & ~1) * 2;
@@ -758,7 +770,7 @@ int run_sgbm(vo_ctx* c)
 
 int launch_sgbm(vo_ctx* c)
 {
-    switch (c->D / 32) {
+    switch (c->Dp / 32) {
     case 1: return run_sgbm<1>(c);
     case 2: return run_sgbm<2>(c);
     case 3: return run_sgbm<3>(c);
@@ -768,7 +780,7 @@ int launch_sgbm(vo_ctx* c)
     case 7: return run_sgbm<7>(c);
     case 8: return run_sgbm<8>(c);
     }
-    return vo_fail(c, VO_ERR_BAD_PARAM, "num_disparities must be a multiple of 32 in [32, 256]");
+    return vo_fail(c, VO_ERR_BAD_PARAM, "num_disparities must be a multiple of 16 in [16, 256]");
 }
 
 int launch_depth_map(vo_ctx* c)

@@ -58,13 +58,13 @@ static int derive(vo_ctx* c)
     if (p.max_batch < 1 || p.max_batch > 1024) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "max_batch %d out of range", p.max_batch);
     if (p.max_features < 16) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "max_features too small");
     if (p.min_disparity != 0) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "min_disparity must be 0");
-    if (p.num_disparities < 32 || p.num_disparities > 256 || p.num_disparities % 32) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "num_disparities must be a multiple of 32 in [32, 256]");
+    if (p.num_disparities < 16 || p.num_disparities > 256 || p.num_disparities % 16) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "num_disparities must be a multiple of 16 in [16, 256]");
     if (p.block_size < 1 || p.block_size > 13 || !(p.block_size & 1)) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "block_size must be odd and <= 13");
     if (p.uniqueness_ratio != 0) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "uniqueness_ratio must be 0");
     if (p.wta_simd_lanes != 0 && p.wta_simd_lanes != 8 && p.wta_simd_lanes != 16) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "wta_simd_lanes must be 0, 8 or 16");
     if (p.lk_win < 3 || p.lk_win > 31 || !(p.lk_win & 1)) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "lk_win must be odd in [3, 31]");
     if (p.lk_max_level < 0 || p.lk_max_level >= VO_MAX_LEVELS) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "lk_max_level out of range");
-    c->W = p.width; c->H = p.height; c->D = p.num_disparities;
+    c->W = p.width; c->H = p.height; c->D = p.num_disparities; c->Dp = (c->D + 31) & ~31;
     c->width1 = c->W - c->D;
     if (c->width1 < 1) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "width must exceed num_disparities");
     c->P1 = p.p1 > 0 ? p.p1 : 2;
@@ -74,6 +74,12 @@ static int derive(vo_ctx* c)
     // packed 16-bit path arithmetic: aggregated cost <= block^2 * 93 and cost + P2 must stay below 32767 - P1
     const int cmax = p.block_size * p.block_size * 93;
     if (cmax > 16383 || c->P2 + cmax + c->P1 > 32767 || c->ftzero > 63) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "P1/P2/block_size exceed the 16-bit cost range");
+    // A disparity range that is a multiple of 16 but not of 32 is padded to the next multiple of 32 with dead cells of
+    // constant cost.  A path cost L obeys C - P2 <= L <= C, so with dead_cost - P2 + P1 > cmax + P2 a dead neighbour is
+    // never the cheapest way into a live cell (the same as the "infinite" cell beyond the range) and never the row minimum.
+    c->dead_cost = 32767 - c->P1 - 1;
+    if (c->Dp != c->D && !(c->dead_cost - c->P2 + c->P1 > cmax + c->P2))
+        return vo_fail(nullptr, VO_ERR_BAD_PARAM, "P1/P2 leave no room for the padding cells of a disparity range that is not a multiple of 32");
     // 4 fixed stripes with a warm-up overlap (the stripe count is fixed so that results do not depend on the machine)
     c->stripe_sz = (int)ceil(c->H / 4.0);
     c->overlap = (p.block_size / 2 + 1) + (int)ceil(0.1 * c->stripe_sz);
@@ -146,7 +152,7 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
         CR(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         CR(hipEventCreateWithFlags(&c->join2, hipEventDisableTiming));
     }
-    const size_t B = c->p.max_batch, W = c->W, H = c->H, D = c->D, w1 = c->width1, F = c->p.max_features;
+    const size_t B = c->p.max_batch, W = c->W, H = c->H, D = c->Dp, w1 = c->width1, F = c->p.max_features;
     c->own_pitch = (W + 63) & ~(size_t)63; c->own_fstride = c->own_pitch * H;
     CR(dalloc(&c->img_own, 4 * B * c->own_fstride));
     CR(dalloc(&c->pre, B * 2 * H * (size_t)vo_pre_pitch(c) * 8 + 4096)); // slack: the wide cost kernel reads a few columns past the last row of halo tiles
@@ -766,7 +772,10 @@ extern "C" int vo_read_tap(vo_ctx* c, int tap, int b, int arg0, int arg1, void* 
         int r = arg1 - c->stripe_y0[arg0];
         if (r < 0 || r >= c->stripe_rows[arg0] || arg1 < arg0 * c->stripe_sz)
             return vo_fail(c, VO_ERR_BAD_ARG, "row %d is not an output row of stripe %d (warm-up rows are not kept)", arg1, arg0);
-        return d2h(c, out, c->cost + (((size_t)b * c->srows + c->stripe_row_off[arg0] + r) * c->width1) * c->D, bytes);
+        VO_HIP(c, hipMemcpy2DAsync(out, (size_t)c->D * 2, c->cost + (((size_t)b * c->srows + c->stripe_row_off[arg0] + r) * c->width1) * c->Dp,
+                                   (size_t)c->Dp * 2, (size_t)c->D * 2, (size_t)c->width1, hipMemcpyDeviceToHost, c->stream));
+        VO_HIP(c, hipStreamSynchronize(c->stream));
+        return VO_OK;
     }
     case VO_TAP_PYR_LEVEL:
     case VO_TAP_DERIV_LEVEL: {

@@ -32,6 +32,9 @@ struct vo_ctx {
 
     // derived
     int W = 0, H = 0, D = 0, width1 = 0;
+    int Dp = 0;        // D rounded up to 32: the disparity stride of the cost volumes and what the kernels are instantiated for;
+                       // cells d >= D carry a cost no path can prefer and are never winners
+    int dead_cost = 0; // that cost
     int stripe_sz = 0, overlap = 0;
     int stripe_y0[4], stripe_rows[4], stripe_row_off[5]; // source row range and offset into the stripe-row volume
     int srows = 0;                                       // rows of the cost volume per frame (sum of stripe rows)
@@ -140,7 +143,7 @@ inline size_t vo_cost_tiles(const vo_ctx* c)
 // pixels per row of the prefiltered images: the width rounded up to the 4 pixels a prefilter thread writes
 inline int vo_pre_pitch(const vo_ctx* c) { return (c->W + 3) & ~3; }
 constexpr int vo_hpath_seg(int pairs_per_lane) { return pairs_per_lane <= 4 ? 16 : 8; }
-inline int vo_hpath_segments(const vo_ctx* c) { const int seg = vo_hpath_seg(c->D / 32); return (c->width1 + seg - 1) / seg; }
+inline int vo_hpath_segments(const vo_ctx* c) { const int seg = vo_hpath_seg(c->Dp / 32); return (c->width1 + seg - 1) / seg; }
 
 // ---- launchers (each enqueues on c->stream, returns a vo_status) ----
 int launch_fast(vo_ctx* c);
