@@ -287,8 +287,13 @@ __global__ __launch_bounds__((CostTile<NP, NCOL_>::THREADS), 4) void cost_vpath_
             for (int k = 0; k < NP; k++) {
                 if (k < k_begin || k >= k_end) continue;
                 const int ia = j - 2 * k + 2 * NP - 1; // slot 2k (lower d); slot 2k+1 is ia - 1
-                const v2s c = bt_pair(g, g0, g1, r[ia].x, r[ia - 1].x) + (bt_pair(w, w0, w1, r[ia].y, r[ia - 1].y) >> 2);
-                V[j][k] = c * sc + V[j][k];
+                // Both halves of every operand below are small and non-negative (a pixel cost is below 2^7, a window sum of 11
+                // of them below 2^11, and a cost that leaves the sum was added to it earlier), so no carry or borrow crosses
+                // the halves: plain 32-bit adds, which issue faster than the packed 16-bit ones.
+                const int c = as_int(bt_pair(g, g0, g1, r[ia].x, r[ia - 1].x)) + as_int(bt_pair(w, w0, w1, r[ia].y, r[ia - 1].y) >> 2);
+                if (scale == 1) V[j][k] = as_v2s(as_int(V[j][k]) + c);
+                else if (scale == -1) V[j][k] = as_v2s(as_int(V[j][k]) - c);
+                else V[j][k] = as_v2s(c) * sc + V[j][k];
             }
         }
     };
@@ -390,12 +395,13 @@ __global__ __launch_bounds__((CostTile<NP, NCOL_>::THREADS), 4) void cost_vpath_
                 v2s col[NC];
 #pragma unroll
                 for (int i = 0; i < NC; i++) col[i] = as_v2s(buf[hbase + i * CS + k * 16]); // beyond the tile only for unused halo columns
-                v2s a = col[0];
+                // 32-bit adds on the packed pairs: every partial sum of window sums stays below 2^15 per half
+                int a = as_int(col[0]);
 #pragma unroll
-                for (int i = 1; i <= 2 * SWC; i++) a += col[i];
-                C[0][k] = a;
+                for (int i = 1; i <= 2 * SWC; i++) a += as_int(col[i]);
+                C[0][k] = as_v2s(a);
 #pragma unroll
-                for (int j = 1; j < NCOL; j++) C[j][k] = C[j - 1][k] + col[j + 2 * SWC] - col[j - 1];
+                for (int j = 1; j < NCOL; j++) C[j][k] = as_v2s(as_int(C[j - 1][k]) + as_int(col[j + 2 * SWC]) - as_int(col[j - 1]));
                 __builtin_amdgcn_sched_barrier(0); // keep the register columns apart: one column's 12 operands live at a time
             }
         } else {
@@ -497,8 +503,12 @@ __global__ __launch_bounds__(256) void hpath_ckpt_kernel(const int16_t* __restri
     }
 }
 
+// 7 and 8 pairs per lane come out just over 256 registers, which is one wavefront per SIMD; held to 256, two fit
+#ifndef VO_HP_WIDE_MIN_WAVES
+#define VO_HP_WIDE_MIN_WAVES 2
+#endif
 template <int NP>
-__global__ __launch_bounds__(64) void hpath_resolve_kernel(const int16_t* __restrict__ cost, const int16_t* __restrict__ ltop, int width1,
+__global__ __launch_bounds__(64, (NP >= 7 ? VO_HP_WIDE_MIN_WAVES : 1)) void hpath_resolve_kernel(const int16_t* __restrict__ cost, const int16_t* __restrict__ ltop, int width1,
                                                             int Dp, int W, int H, int srows, StripeInfo si, int stripe_sz, int P1, int P2,
                                                             int tie_lanes, int nseg, const int* __restrict__ ckpt, int32_t* __restrict__ wta, int D)
 {
