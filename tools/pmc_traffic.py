@@ -2,7 +2,7 @@
 """Turns two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; one counter_collection.csv each) into
 profiles/traffic.json: HBM bytes per launch of each kernel, keyed by bench.py's stage names.
 
-    tools/pmc_traffic.py WORKLOAD FETCH.csv WRITE.csv [ROUND_TAG]
+    tools/pmc_traffic.py WORKLOAD FETCH.csv WRITE.csv [ROUND_TAG [BATCH]]      (BATCH: frame pairs per launch of the profiled run)
 
 Counter units are KiB.  On gfx950 FETCH_SIZE counts a 128-byte request as 64 bytes, so fetches are doubled;
 the correction was checked on hpath_kernel, whose reads are known exactly (two s16 volumes per launch).
@@ -38,6 +38,7 @@ def per_kernel(path):
 def main():
     workload, fetch_csv, write_csv = sys.argv[1:4]
     tag = sys.argv[4] if len(sys.argv) > 4 else ""
+    batch = int(sys.argv[5]) if len(sys.argv) > 5 else (8 if workload == "4k" else 16)
     F, W = per_kernel(fetch_csv), per_kernel(write_csv)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out_path = os.path.join(root, "profiles", "traffic.json")
@@ -49,6 +50,7 @@ def main():
         if k in STAGE:
             entry[STAGE[k]] = fetch + write
     data[workload] = entry
+    data[workload + "_batch"] = batch
     data[workload + "_detail"] = {"per_kernel_per_launch": detail, "source": tag,
                                   "note": "FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), WRITE_SIZE KiB x 1024"}
     json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)

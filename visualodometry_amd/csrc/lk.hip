@@ -134,7 +134,7 @@ __device__ __forceinline__ int cv_round(float v) { return __float2int_rn(v); }
 struct LkArgs {
     PyrArgs pa;
     int win, max_count, max_features;
-    int groups_per_frame, n_frames; // 16-feature groups a frame is given blocks for; frames in the batch
+    int slots_per_frame, n_frames;  // blocks an XCD is given per frame (one eighth of the 16-feature groups); frames in the batch
     float min_eig;
     double eps2;
 };
@@ -254,15 +254,18 @@ __global__ __launch_bounds__(256, (NR == 1 ? VO_LK_MIN_WAVES : 1)) void lk_row_k
     constexpr int NPX = 4 * NDW - 1;   // pixel slots per window row (win <= NPX)
     constexpr int NPP = 2 * NDW;       // slot pairs per window row
     const int lane16 = threadIdx.x & 15;
-    // Blocks are dealt round-robin over the 8 XCDs, each with its own L2.  Block id -> (frame, feature group) is chosen
-    // so that one XCD walks a contiguous run of feature groups: neighbouring features (row-major order) read
-    // overlapping window rows of the same pyramids, and a frame's pyramids are then cached by one L2, not by eight.
-    const int per_xcd = (a.groups_per_frame * a.n_frames + 7) / 8;
-    const int gid = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if (gid >= a.groups_per_frame * a.n_frames) return;
-    const int b = gid / a.groups_per_frame, fgroup = gid % a.groups_per_frame;
-    const int i = fgroup * 16 + (threadIdx.x >> 4);
+    // Blocks are dealt round-robin over the 8 XCDs, each with its own L2.  An XCD takes one eighth of every frame's feature
+    // groups, a contiguous run of them: neighbouring features (row-major order) read overlapping window rows of the same
+    // pyramids, so an XCD's L2 holds a band of each frame's pyramids instead of all of them, and the eight XCDs get the same
+    // amount of work whatever the number of frames and however many features each frame has.
+    const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
+    const int b = slot / a.slots_per_frame, t = slot % a.slots_per_frame;
+    if (b >= a.n_frames) return;
     const int nf = n_feat[b];
+    const int groups = (nf + 15) >> 4, per_xcd = (groups + 7) >> 3;
+    const int fgroup = xcd * per_xcd + t;
+    if (t >= per_xcd || fgroup >= groups) return;
+    const int i = fgroup * 16 + (threadIdx.x >> 4);
     if (fgroup * 16 + (int)(threadIdx.x >> 6) * 4 >= nf) return; // uniform per wavefront
     const bool have = i < nf;
     const int win = a.win;
@@ -510,8 +513,8 @@ int launch_match_klt(vo_ctx* c, bool counts_on_host)
     if (counts_on_host) for (int b = 0; b < c->n; b++) nmax = std::max(nmax, c->h_nfeat[b]);
     if (nmax > 0) {
         StageTimer st_(c, VO_ST_LK);
-        a.groups_per_frame = (nmax + 15) / 16; a.n_frames = c->n;
-        dim3 g16(8 * ((a.groups_per_frame * c->n + 7) / 8)), blk16(256);
+        a.slots_per_frame = ((nmax + 15) / 16 + 7) / 8; a.n_frames = c->n;
+        dim3 g16(8 * a.slots_per_frame * c->n), blk16(256);
         if (a.win <= 15) hipLaunchKernelGGL((lk_row_kernel<1, 4>), g16, blk16, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
         else if (a.win <= 23) hipLaunchKernelGGL((lk_row_kernel<2, 6>), g16, blk16, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
         else hipLaunchKernelGGL((lk_row_kernel<2, 8>), g16, blk16, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
