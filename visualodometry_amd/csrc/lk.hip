@@ -254,17 +254,18 @@ __global__ __launch_bounds__(256, (NR == 1 ? VO_LK_MIN_WAVES : 1)) void lk_row_k
     constexpr int NPX = 4 * NDW - 1;   // pixel slots per window row (win <= NPX)
     constexpr int NPP = 2 * NDW;       // slot pairs per window row
     const int lane16 = threadIdx.x & 15;
-    // Blocks are dealt round-robin over the 8 XCDs, each with its own L2.  An XCD takes one eighth of every frame's feature
-    // groups, a contiguous run of them: neighbouring features (row-major order) read overlapping window rows of the same
-    // pyramids, so an XCD's L2 holds a band of each frame's pyramids instead of all of them, and the eight XCDs get the same
-    // amount of work whatever the number of frames and however many features each frame has.
+    // Blocks are dealt round-robin over the 8 XCDs, each with its own L2.  A frame's 16-feature groups are cut into runs of
+    // LK_RUN consecutive groups and the runs are dealt to the XCDs in turn: neighbouring features (row-major order) read
+    // overlapping window rows of the same pyramids, so a run shares its rows in one L2, and every XCD gets the same share of
+    // every frame and of every image region, whatever the number of frames and however many features each frame has.
+    constexpr int LK_RUN = 4;
     const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
     const int b = slot / a.slots_per_frame, t = slot % a.slots_per_frame;
     if (b >= a.n_frames) return;
     const int nf = n_feat[b];
-    const int groups = (nf + 15) >> 4, per_xcd = (groups + 7) >> 3;
-    const int fgroup = xcd * per_xcd + t;
-    if (t >= per_xcd || fgroup >= groups) return;
+    const int groups = (nf + 15) >> 4;
+    const int fgroup = ((t / LK_RUN) * 8 + xcd) * LK_RUN + t % LK_RUN;
+    if (fgroup >= groups) return;
     const int i = fgroup * 16 + (threadIdx.x >> 4);
     if (fgroup * 16 + (int)(threadIdx.x >> 6) * 4 >= nf) return; // uniform per wavefront
     const bool have = i < nf;
@@ -513,7 +514,7 @@ int launch_match_klt(vo_ctx* c, bool counts_on_host)
     if (counts_on_host) for (int b = 0; b < c->n; b++) nmax = std::max(nmax, c->h_nfeat[b]);
     if (nmax > 0) {
         StageTimer st_(c, VO_ST_LK);
-        a.slots_per_frame = ((nmax + 15) / 16 + 7) / 8; a.n_frames = c->n;
+        a.slots_per_frame = (((nmax + 15) / 16 + 31) / 32) * 4; a.n_frames = c->n; // runs of 4 groups, dealt over 8 XCDs
         dim3 g16(8 * a.slots_per_frame * c->n), blk16(256);
         if (a.win <= 15) hipLaunchKernelGGL((lk_row_kernel<1, 4>), g16, blk16, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
         else if (a.win <= 23) hipLaunchKernelGGL((lk_row_kernel<2, 6>), g16, blk16, 0, c->stream, a, c->pyr, c->der, c->feat, c->n_feat, c->legs, c->leg_status);
