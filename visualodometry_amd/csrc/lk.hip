@@ -180,13 +180,17 @@ __device__ __forceinline__ int pair_shr9(int lo, int hi)
     return __builtin_bit_cast(int, t >> (short)1);
 }
 
+// hi * 2^16 + lo as the float nearest to that integer, for |hi|, |lo| < 2^24: both convert exactly and the fused
+// multiply-add rounds the exact sum once, which is what rounding the 64-bit integer would give
+__device__ __forceinline__ float sum_of_halves(int hi, int lo) { return __builtin_fmaf((float)hi, 65536.f, (float)lo); }
+
 // exact sum over the 16 lanes of a group, as the float nearest to the integer (every lane gets it)
 __device__ __forceinline__ float group_sum(int v)
 {
     int lo = v & 0xffff, hi = v >> 16;
     lo = DPP_ADD(lo, 0xB1); lo = DPP_ADD(lo, 0x4E); lo = DPP_ADD(lo, 0x141); lo = DPP_ADD(lo, 0x140);
     hi = DPP_ADD(hi, 0xB1); hi = DPP_ADD(hi, 0x4E); hi = DPP_ADD(hi, 0x141); hi = DPP_ADD(hi, 0x140);
-    return (float)((double)hi * 65536.0 + (double)lo);
+    return sum_of_halves(hi, lo);
 }
 
 // two sums at once: four independent DPP chains, stepped together so no step waits on the previous one
@@ -214,8 +218,8 @@ __device__ __forceinline__ void group_sum2(int u, int v, float& su, float& sv)
 #pragma unroll
         for (int q = 0; q < 4; q++) c[q] += t[q];
     }
-    su = (float)((double)c[1] * 65536.0 + (double)c[0]);
-    sv = (float)((double)c[3] * 65536.0 + (double)c[2]);
+    su = sum_of_halves(c[1], c[0]);
+    sv = sum_of_halves(c[3], c[2]);
 }
 
 // the 4*NDW-1 pairs (p[x], p[x+1]) of one source row, each as two zero-extended 16-bit halves
@@ -276,6 +280,7 @@ __global__ __launch_bounds__(256, (NR == 1 ? VO_LK_MIN_WAVES : 1)) void lk_row_k
     vo_point2f prev0 = feat[(size_t)b * a.max_features + min(i, nf - 1)];
     const int nl = a.pa.nlevels;
     const float FLT_SCALE = 1.f / (float)(1 << 20);
+    const float eps2_lo = (float)(a.eps2 * (1.0 - 1e-6)), eps2_hi = (float)(a.eps2 * (1.0 + 1e-6));
 
     for (int leg = 0; leg < 4; leg++) {
         const uint8_t* Ibase = pyr + ((size_t)b * a.pa.img_per_b + leg_prev[leg]) * a.pa.pyr_bytes;
@@ -395,8 +400,16 @@ __global__ __launch_bounds__(256, (NR == 1 ? VO_LK_MIN_WAVES : 1)) void lk_row_k
                         const float dx_ = (A12 * b2 - A22 * b1) * Dt, dy_ = (A12 * b1 - A11 * b2) * Dt;
                         qx += dx_; qy += dy_;
                         nx = qx + half; ny = qy + half;
-                        if ((double)dx_ * (double)dx_ + (double)dy_ * (double)dy_ <= a.eps2) it = false;
-                        else if (j > 0 && (double)fabsf(dx_ + pdx) < 0.01 && (double)fabsf(dy_ + pdy) < 0.01) {
+                        // |delta|^2 <= eps^2 is a double-precision test in the original.  The single-precision value is within
+                        // 2^-22 of it, so only a value inside that band around the threshold needs the exact test, and the
+                        // wavefront runs it only if one of its lanes is there.
+                        const float d2 = __builtin_fmaf(dx_, dx_, dy_ * dy_);
+                        bool small = d2 < eps2_lo;
+                        const bool unsure = !small && !(d2 > eps2_hi);
+                        if (__any(unsure)) small = small || (unsure && (double)dx_ * (double)dx_ + (double)dy_ * (double)dy_ <= a.eps2);
+                        // (double)|x| < 0.01 holds exactly for the floats up to 0.01f, the float just below 0.01
+                        if (small) it = false;
+                        else if (j > 0 && fabsf(dx_ + pdx) <= 0.01f && fabsf(dy_ + pdy) <= 0.01f) {
                             nx -= dx_ * 0.5f; ny -= dy_ * 0.5f;
                             it = false;
                         }
