@@ -280,9 +280,11 @@ def parse_args(argv):
     ap.add_argument("--latency", action="store_true",
                     help="also time one frame pair alone (batch of 1) after the run; off by default so that a kernel profile "
                          "of the default command holds launches of one batch size only")
-    ap.add_argument("--mode", default="pairs", choices=["pairs", "sequence"],
-                    help="pairs: B independent frame pairs, 4 pyramids each (what the reference rebuilds per step); "
-                         "sequence: B + 1 consecutive frames, every frame pyramided once")
+    ap.add_argument("--mode", default="sequence", choices=["pairs", "sequence"],
+                    help="sequence (default): a step's window is B + 1 consecutive frames of the rank's sequence, handed over as such; "
+                         "every frame is uploaded and pyramided once and serves as T2 of one pair and T1 of the next (same results). "
+                         "pairs: the same window handed over as B independent frame pairs, 4 images and 4 pyramids each "
+                         "(what the reference rebuilds on every step)")
     ap.add_argument("--rehearse", action="store_true",
                     help="more ranks than GPUs: rank r uses GPU r mod (GPUs present) and the gather runs over gloo (plumbing rehearsal)")
     ap.add_argument("--stub-context", action="store_true", help="plumbing test without a GPU: no kernels run, the value is meaningless")

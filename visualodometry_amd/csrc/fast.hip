@@ -2,9 +2,10 @@
 // Replaces cv::FAST(img, keypoints, threshold, true) + KeyPoint::convert as used by
 // VOClass::getFeaturesFAST (reference Source/VOClassFeatures.cpp:27-32).
 //
-//  fast_score_kernel  : one thread per pixel, 64x16 tile (+3 halo) staged in LDS; the 16 ring pixels are
-//                       turned into a bright and a dark 16-bit mask, "9 contiguous" is a shift-and-AND test,
-//                       the corner score is the closed form max(t, max_arc min(d), max_arc min(-d)) - 1.
+//  fast_score_kernel  : 64x16 tile (+3 halo) staged in LDS; a four-pair necessary test on every pixel, then, for the
+//                       pixels that pass only: the 16 ring pixels are turned into a bright and a dark 16-bit mask,
+//                       "9 contiguous" is a shift-and-AND test, the corner score is the closed form
+//                       max(t, max_arc min(d), max_arc min(-d)) - 1.
 //  fast_count_kernel  : per image row, number of pixels whose score is a strict 3x3 maximum.
 //  fast_write_kernel  : per image row, the sum of the counts of the rows above is the row's offset; wavefront ballot +
 //                       prefix popcount gives every keypoint its rank, so the output order is y-major, x-minor,
@@ -36,14 +37,21 @@ __device__ __forceinline__ int sliding_min9_max(const int d[16])
     return best;
 }
 
+// Two phases per 64 x 16 tile.  Phase 1, every pixel: the cheap necessary condition.  An arc of 9 of the 16 ring pixels holds
+// at least one pixel of every antipodal pair, so a corner has, for every pair, a member brighter than v + t (or, for a dark
+// arc, a member darker than v - t); four pairs are tested.  The few pixels that pass are appended to a list in LDS (ballot
+// ranks, one LDS atomic per wavefront).  Phase 2, the listed pixels only, all lanes busy: the full ring test and the score.
 __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restrict__ img, size_t pitch, size_t fstride,
                                                          int W, int H, int thr, int nms, uint8_t* __restrict__ score)
 {
     __shared__ uint8_t tile[LDS_H][LDS_W];
+    __shared__ unsigned short cand[TILE_W * TILE_H];
+    __shared__ int ncand;
     const int b = blockIdx.z;
     const uint8_t* src = img + (size_t)b * fstride;
     const int x0 = blockIdx.x * TILE_W - HALO, y0 = blockIdx.y * TILE_H - HALO;
     const int tid = threadIdx.y * TILE_W + threadIdx.x;
+    if (tid == 0) ncand = 0;
     for (int i = tid; i < LDS_H * (TILE_W + 2 * HALO); i += 256) {
         int ty = i / (TILE_W + 2 * HALO), tx = i - ty * (TILE_W + 2 * HALO);
         int gx = x0 + tx, gy = y0 + ty;
@@ -53,47 +61,70 @@ __global__ __launch_bounds__(256) void fast_score_kernel(const uint8_t* __restri
     }
     __syncthreads();
     const int x = blockIdx.x * TILE_W + threadIdx.x;
+    uint8_t* dst = score + (size_t)b * H * W;
 #pragma unroll
     for (int r = 0; r < TILE_H / 4; r++) {
         const int ly = threadIdx.y + r * 4;
         const int y = blockIdx.y * TILE_H + ly;
-        if (x >= W || y >= H) continue;
-        uint8_t out = 0;
+        bool pass = false;
         if (x >= 3 && x < W - 3 && y >= 3 && y < H - 3) {
             const int cx = threadIdx.x + HALO, cy = ly + HALO;
-            const int v = tile[cy][cx];
-            int ring[16];
-            ring[0] = tile[cy + 3][cx];      ring[1] = tile[cy + 3][cx + 1];  ring[2] = tile[cy + 2][cx + 2];
-            ring[3] = tile[cy + 1][cx + 3];  ring[4] = tile[cy][cx + 3];      ring[5] = tile[cy - 1][cx + 3];
-            ring[6] = tile[cy - 2][cx + 2];  ring[7] = tile[cy - 3][cx + 1];  ring[8] = tile[cy - 3][cx];
-            ring[9] = tile[cy - 3][cx - 1];  ring[10] = tile[cy - 2][cx - 2]; ring[11] = tile[cy - 1][cx - 3];
-            ring[12] = tile[cy][cx - 3];     ring[13] = tile[cy + 1][cx - 3]; ring[14] = tile[cy + 2][cx - 2];
-            ring[15] = tile[cy + 3][cx - 1];
-            unsigned dark = 0, bright = 0;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                dark |= (unsigned)(ring[k] < v - thr) << k;
-                bright |= (unsigned)(ring[k] > v + thr) << k;
-            }
-            auto arc9 = [](unsigned m) {
-                unsigned mm = m | (m << 16);
-                unsigned t = mm & (mm >> 1);
-                t &= t >> 2;
-                t &= t >> 4;
-                t &= mm >> 8;
-                return (t & 0xffffu) != 0;
-            };
-            if (arc9(dark) || arc9(bright)) {
-                if (nms) {
-                    int d[16], e[16];
-#pragma unroll
-                    for (int k = 0; k < 16; k++) { d[k] = v - ring[k]; e[k] = -d[k]; }
-                    int a = sliding_min9_max(d), bm = sliding_min9_max(e);
-                    out = (uint8_t)(max(thr, max(a, bm)) - 1);
-                } else out = 1;
-            }
+            const int v = tile[cy][cx], lo = v - thr, hi = v + thr;
+            auto cls = [&](int p) { return (p > hi ? 1 : 0) | (p < lo ? 2 : 0); };
+            int m = cls(tile[cy + 3][cx]) | cls(tile[cy - 3][cx]);
+            m &= cls(tile[cy][cx + 3]) | cls(tile[cy][cx - 3]);
+            m &= cls(tile[cy + 2][cx + 2]) | cls(tile[cy - 2][cx - 2]);
+            m &= cls(tile[cy - 2][cx + 2]) | cls(tile[cy + 2][cx - 2]);
+            pass = m != 0;
         }
-        score[((size_t)b * H + y) * W + x] = out;
+        if (x < W && y < H && !pass) dst[(size_t)y * W + x] = 0;
+        const unsigned long long bal = __ballot(pass);
+        if (bal) { // uniform per wavefront
+            const int lane = tid & 63;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&ncand, __popcll(bal));
+            base = __shfl(base, 0);
+            if (pass) cand[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)(ly * TILE_W + threadIdx.x);
+        }
+    }
+    __syncthreads();
+    const int total = ncand;
+    for (int i = tid; i < total; i += 256) {
+        const int lx = cand[i] % TILE_W, ly = cand[i] / TILE_W;
+        const int cx = lx + HALO, cy = ly + HALO;
+        const int v = tile[cy][cx];
+        int ring[16];
+        ring[0] = tile[cy + 3][cx];      ring[1] = tile[cy + 3][cx + 1];  ring[2] = tile[cy + 2][cx + 2];
+        ring[3] = tile[cy + 1][cx + 3];  ring[4] = tile[cy][cx + 3];      ring[5] = tile[cy - 1][cx + 3];
+        ring[6] = tile[cy - 2][cx + 2];  ring[7] = tile[cy - 3][cx + 1];  ring[8] = tile[cy - 3][cx];
+        ring[9] = tile[cy - 3][cx - 1];  ring[10] = tile[cy - 2][cx - 2]; ring[11] = tile[cy - 1][cx - 3];
+        ring[12] = tile[cy][cx - 3];     ring[13] = tile[cy + 1][cx - 3]; ring[14] = tile[cy + 2][cx - 2];
+        ring[15] = tile[cy + 3][cx - 1];
+        unsigned dark = 0, bright = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            dark |= (unsigned)(ring[k] < v - thr) << k;
+            bright |= (unsigned)(ring[k] > v + thr) << k;
+        }
+        auto arc9 = [](unsigned m) {
+            unsigned mm = m | (m << 16);
+            unsigned t = mm & (mm >> 1);
+            t &= t >> 2;
+            t &= t >> 4;
+            t &= mm >> 8;
+            return (t & 0xffffu) != 0;
+        };
+        uint8_t out = 0;
+        if (arc9(dark) || arc9(bright)) {
+            if (nms) {
+                int d[16], e[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) { d[k] = v - ring[k]; e[k] = -d[k]; }
+                int a = sliding_min9_max(d), bm = sliding_min9_max(e);
+                out = (uint8_t)(max(thr, max(a, bm)) - 1);
+            } else out = 1;
+        }
+        dst[(size_t)(blockIdx.y * TILE_H + ly) * W + blockIdx.x * TILE_W + lx] = out;
     }
 }
 

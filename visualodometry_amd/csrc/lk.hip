@@ -440,7 +440,9 @@ __global__ __launch_bounds__(256) void filter_kernel(const vo_point2f* __restric
                                                      uint8_t* __restrict__ leg_status, vo_point2f* __restrict__ m1, vo_point2f* __restrict__ m2,
                                                      int* __restrict__ n_match)
 {
-    __shared__ int wcnt[4];
+    // One 256-thread block per frame (a wider block would wait for a whole CU to drain while other batches' kernels hold
+    // the wavefront slots).  A trip takes 1024 features, four per thread, so that their loads are in flight together.
+    __shared__ int wcnt[4][4];
     const int b = blockIdx.x, n = n_feat[b];
     const size_t F = max_features;
     const vo_point2f* f0 = feat + (size_t)b * F;
@@ -448,37 +450,49 @@ __global__ __launch_bounds__(256) void filter_kernel(const vo_point2f* __restric
     uint8_t* st = leg_status + (size_t)b * 4 * F;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int base = 0;
-    for (int i0 = 0; i0 < n; i0 += 256) {
-        const int i = i0 + threadIdx.x;
-        bool keep = false;
-        vo_point2f p3 = {0.f, 0.f}, p2 = {0.f, 0.f};
-        if (i < n) {
-            int ok = 1;
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        bool keep[4];
+        vo_point2f p3[4], p2[4];
+        unsigned long long mk[4];
 #pragma unroll
-            for (int leg = 0; leg < 4; leg++) {
-                vo_point2f q = lg[(size_t)leg * F + i];
-                int s = st[(size_t)leg * F + i];
-                if (q.x < 0.f || q.x > fw || q.y < 0.f || q.y > fh) { s = 0; st[(size_t)leg * F + i] = 0; }
-                ok &= (s == 1);
-                if (leg == 2) p2 = q;
-                if (leg == 3) p3 = q;
+        for (int k = 0; k < 4; k++) {
+            const int i = i0 + k * 256 + threadIdx.x;
+            keep[k] = false;
+            p3[k] = {0.f, 0.f}; p2[k] = {0.f, 0.f};
+            if (i < n) {
+                int ok = 1;
+#pragma unroll
+                for (int leg = 0; leg < 4; leg++) {
+                    vo_point2f q = lg[(size_t)leg * F + i];
+                    int s = st[(size_t)leg * F + i];
+                    if (q.x < 0.f || q.x > fw || q.y < 0.f || q.y > fh) { s = 0; st[(size_t)leg * F + i] = 0; }
+                    ok &= (s == 1);
+                    if (leg == 2) p2[k] = q;
+                    if (leg == 3) p3[k] = q;
+                }
+                vo_point2f o = f0[i];
+                int offset = (int)fmaxf(fabsf(o.x - p3[k].x), fabsf(o.y - p3[k].y));
+                keep[k] = ok && offset < loop_thr;
             }
-            vo_point2f o = f0[i];
-            int offset = (int)fmaxf(fabsf(o.x - p3.x), fabsf(o.y - p3.y));
-            keep = ok && offset < loop_thr;
         }
-        unsigned long long mk = __ballot(keep);
-        if (lane == 0) wcnt[wave] = __popcll(mk);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            mk[k] = __ballot(keep[k]);
+            if (lane == 0) wcnt[k][wave] = __popcll(mk[k]);
+        }
         __syncthreads();
-        int before = 0;
-        for (int w = 0; w < wave; w++) before += wcnt[w];
-        const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        if (keep) {
-            int r = base + before + __popcll(mk & ((1ull << lane) - 1ull));
-            m1[(size_t)b * F + r] = p3;
-            m2[(size_t)b * F + r] = p2;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { // chunk k holds features i0 + 256 k ..: ranks follow the feature order
+            int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) { before += w < wave ? wcnt[k][w] : 0; total += wcnt[k][w]; }
+            if (keep[k]) {
+                int r = base + before + __popcll(mk[k] & ((1ull << lane) - 1ull));
+                m1[(size_t)b * F + r] = p3[k];
+                m2[(size_t)b * F + r] = p2[k];
+            }
+            base += total;
         }
-        base += total;
         __syncthreads();
     }
     if (threadIdx.x == 0) n_match[b] = base;
