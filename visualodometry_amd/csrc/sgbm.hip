@@ -634,23 +634,25 @@ __global__ __launch_bounds__(64, (NP >= 7 ? VO_HP_WIDE_MIN_WAVES : NP == 3 ? VO_
 }
 
 // ---------------------------------------------------------------- right-view disparity + consistency check + 3x3 median
-// One block per image row y.  The median needs the checked rows y-1, y, y+1 (replicated at the image border), so the block
-// runs the consistency check of those three rows itself (a row's check is a scatter and a gather over W packed winners,
-// far cheaper than a launch): per row, the right-view disparity by an order-independent LDS atomic-min scatter (smallest
-// cost, then largest x), then the two-sided test.  The centre row is also kept as the pre-median map.
+// One block per LM_ROWS image rows.  The median of row y needs the checked rows y-1, y, y+1 (replicated at the image border),
+// so the block runs the consistency check of its rows and of the row above and below them itself (a row's check is a scatter
+// and a gather over W packed winners, far cheaper than a launch): per row, the right-view disparity by an order-independent
+// LDS atomic-min scatter (smallest cost, then largest x), then the two-sided test.  The checked rows are also the pre-median map.
 #define CSWAP(a, b) { int t_ = min(a, b); b = max(a, b); a = t_; }
+constexpr int LM_ROWS = 4; // image rows per block: LM_ROWS + 2 rows are checked for them
 __global__ __launch_bounds__(256) void lrmedian_kernel(const int32_t* __restrict__ wta, int W, int H, int width1, int srows,
                                                        StripeInfo si, int stripe_sz, int disp12, int16_t* __restrict__ disp_pre,
                                                        int16_t* __restrict__ dst, float* __restrict__ dstf)
 {
-    extern __shared__ unsigned lm_sm[]; // key[W], then three rows of checked disparities (int16, W rounded up to 2)
+    extern __shared__ unsigned lm_sm[]; // key[W], then LM_ROWS + 2 rows of checked disparities (int16, W rounded up to 2)
     unsigned* key = lm_sm;
     const int Wr = (W + 1) & ~1;
     int16_t* res = reinterpret_cast<int16_t*>(lm_sm + W);
-    const int y = blockIdx.x, b = blockIdx.y;
+    const int y0 = blockIdx.x * LM_ROWS, b = blockIdx.y;
     const int minX1 = W - width1;
-    for (int t = 0; t < 3; t++) {
-        const int yy = min(max(y - 1 + t, 0), H - 1);
+    for (int t = 0; t < LM_ROWS + 2; t++) {
+        if (y0 - 1 + t > H) break; // uniform: past the row below the block's last image row
+        const int yy = min(max(y0 - 1 + t, 0), H - 1);
         const int stripe = min(yy / stripe_sz, 3);
         const int sr = si.off[stripe] + (yy - si.y0[stripe]);
         const int32_t* w = wta + ((size_t)b * srows + sr) * W;
@@ -689,12 +691,15 @@ __global__ __launch_bounds__(256) void lrmedian_kernel(const int32_t* __restrict
         }
         __syncthreads(); // the key array is reused by the next row; res is read below
     }
-    const size_t o0 = ((size_t)b * H + y) * W;
-    for (int x = threadIdx.x; x < W; x += 256) {
+    for (int i = threadIdx.x; i < LM_ROWS * W; i += 256) {
+        const int ry = i / W, x = i - ry * W;
+        if (y0 + ry >= H) break; // rows ascend with i
+        const size_t o0 = ((size_t)b * H + y0 + ry) * W;
+        const int16_t* r0 = res + ry * Wr;
         const int x0 = max(x - 1, 0), x2 = min(x + 1, W - 1);
-        int p0 = res[x0], p1 = res[x], p2 = res[x2];
-        int p3 = res[Wr + x0], p4 = res[Wr + x], p5 = res[Wr + x2];
-        int p6 = res[2 * Wr + x0], p7 = res[2 * Wr + x], p8 = res[2 * Wr + x2];
+        int p0 = r0[x0], p1 = r0[x], p2 = r0[x2];
+        int p3 = r0[Wr + x0], p4 = r0[Wr + x], p5 = r0[Wr + x2];
+        int p6 = r0[2 * Wr + x0], p7 = r0[2 * Wr + x], p8 = r0[2 * Wr + x2];
         disp_pre[o0 + x] = (int16_t)p4;
         CSWAP(p1, p2); CSWAP(p4, p5); CSWAP(p7, p8); CSWAP(p0, p1); CSWAP(p3, p4); CSWAP(p6, p7);
         CSWAP(p1, p2); CSWAP(p4, p5); CSWAP(p7, p8); CSWAP(p0, p3); CSWAP(p5, p8); CSWAP(p4, p7);
@@ -766,13 +771,13 @@ int run_sgbm(vo_ctx* c)
                        c->stripe_sz, c->P1, c->P2, c->p.wta_simd_lanes, nseg, c->ckpt, c->wta, c->D);
     }
     { StageTimer st_(c, VO_ST_LRCHECK);
-    const size_t lm_lds = (size_t)W * 4 + (size_t)3 * ((W + 1) & ~1) * 2;
+    const size_t lm_lds = (size_t)W * 4 + (size_t)(LM_ROWS + 2) * ((W + 1) & ~1) * 2;
     static std::atomic<int> lm_attr[64];
     if (lm_lds > 48 * 1024 && lm_attr[c->device & 63].load(std::memory_order_acquire) < (int)lm_lds) {
         VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&lrmedian_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm_lds));
         lm_attr[c->device & 63].store((int)lm_lds, std::memory_order_release);
     }
-    hipLaunchKernelGGL(lrmedian_kernel, dim3(H, n), dim3(256), lm_lds, c->stream, c->wta, W, H, w1, c->srows, si, c->stripe_sz,
+    hipLaunchKernelGGL(lrmedian_kernel, dim3((H + LM_ROWS - 1) / LM_ROWS, n), dim3(256), lm_lds, c->stream, c->wta, W, H, w1, c->srows, si, c->stripe_sz,
                        c->disp12, c->disp_pre, c->disp16, c->disp32);
     }
     VO_HIP(c, hipGetLastError());
