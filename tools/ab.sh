@@ -9,6 +9,6 @@ for i in $(seq $rounds); do
     timeout -k 10 200 python3 $root/bench.py --frame-cache /tmp/vo_frames --no-cpu --no-upload-leg --steps ${AB_STEPS:-100} $AB_FLAGS 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); s=d['config']['stage_ms_one_batch_in_flight']
-print('$v', round(d['value'],1), ' '.join('%s=%.3f'%(k.replace('sgbm_',''),s[k]) for k in ('sgbm_cost_vpath','sgbm_hpath_ckpt','sgbm_hpath_resolve','lk','pyramid','fast')))" || exit 1
+print('$v', round(d['value'],1), ' '.join('%s=%.3f'%(k.replace('sgbm_',''),s[k]) for k in ('sgbm_cost_vpath','sgbm_hpath_ckpt','sgbm_hpath_resolve','lk','pyramid','fast','sgbm_prefilter','sgbm_lrcheck_median','klt_filter')))" || exit 1
   done
 done

@@ -56,18 +56,31 @@ __global__ __launch_bounds__(256) void prefilter_kernel(const uint8_t* __restric
                                                         size_t pitch, size_t fstride, int W, int H, int Wp, int ftzero,
                                                         uint4* __restrict__ pre)
 {
-    const int x0 = (blockIdx.x * PF_T + (threadIdx.x & (PF_T - 1))) * PF_N, y = blockIdx.y * PF_R + (threadIdx.x / PF_T);
+    // the block's source pixels (its 4 rows and the rows above and below, its 256 columns and two more on each side, all
+    // clamped to the image) go through LDS: 6 coalesced byte loads per thread instead of 24 strided ones
+    constexpr int PF_COLS = PF_T * PF_N + 4, PF_PITCH = PF_COLS + 4;
+    __shared__ __attribute__((aligned(4))) uint8_t tile[(PF_R + 2) * PF_PITCH];
     const int b = blockIdx.z >> 1, which = blockIdx.z & 1;
-    if (x0 >= W || y >= H) return;
     const uint8_t* img = (which ? right : left) + (size_t)b * fstride;
-    const uint8_t* r1 = img + (size_t)y * pitch;
-    const uint8_t* r0 = y > 0 ? r1 - pitch : r1;
-    const uint8_t* r2 = y < H - 1 ? r1 + pitch : r1;
+    const int bx = blockIdx.x * PF_T * PF_N, by = blockIdx.y * PF_R;
+    for (int i = threadIdx.x; i < (PF_R + 2) * PF_COLS; i += 256) {
+        const int ry = i / PF_COLS, cx = i - ry * PF_COLS;
+        const int gx = min(max(bx - 2 + cx, 0), W - 1), gy = min(max(by - 1 + ry, 0), H - 1);
+        tile[ry * PF_PITCH + cx] = img[(size_t)gy * pitch + gx];
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & (PF_T - 1), ty = threadIdx.x / PF_T;
+    const int x0 = bx + tx * PF_N, y = by + ty;
+    if (x0 >= W || y >= H) return;
     int a0[PF_N + 4], a1[PF_N + 4], a2[PF_N + 4]; // columns x0-2 .. x0+5; a clamped column is never used (border rule)
+    {
+        const unsigned* q0 = reinterpret_cast<const unsigned*>(tile + ty * PF_PITCH + tx * PF_N);
+        const unsigned* q1 = reinterpret_cast<const unsigned*>(tile + (ty + 1) * PF_PITCH + tx * PF_N);
+        const unsigned* q2 = reinterpret_cast<const unsigned*>(tile + (ty + 2) * PF_PITCH + tx * PF_N);
 #pragma unroll
-    for (int i = 0; i < PF_N + 4; i++) {
-        const int xc = min(max(x0 - 2 + i, 0), W - 1);
-        a0[i] = r0[xc]; a1[i] = r1[xc]; a2[i] = r2[xc];
+        for (int i = 0; i < PF_N + 4; i++) {
+            a0[i] = (q0[i >> 2] >> (8 * (i & 3))) & 0xff; a1[i] = (q1[i >> 2] >> (8 * (i & 3))) & 0xff; a2[i] = (q2[i >> 2] >> (8 * (i & 3))) & 0xff;
+        }
     }
     int g[PF_N + 2], r[PF_N + 2]; // columns x0-1 .. x0+4
 #pragma unroll
