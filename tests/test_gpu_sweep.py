@@ -134,3 +134,42 @@ def test_batch_with_a_textureless_pair_in_the_middle():
     Rt1, _ = one.step()
     assert np.array_equal(Rt1[0], Rt[2])
     one.close(); ctx.close()
+
+
+def test_odd_batch_equals_pairs_processed_alone():
+    """11 frame pairs in one batch (not a multiple of anything a kernel tiles by: the tracker deals feature groups over 8 XCDs,
+    the disparity kernels pack 4 rows per wavefront, the LR check 4 rows per block), pairs with different corner counts:
+    every pair's matches and pose are bit-identical to the same pair processed alone, for both forms of input"""
+    W, H, B = 283, 78, 11
+    seq = synth.Sequence(seed=777, width=W, height=H)
+    f = [seq.frame(i) for i in range(B + 1)]
+    left = np.stack([x[0] for x in f]); right = np.stack([x[1] for x in f])
+    # different corner counts per pair: blank out growing parts of some left images (both views of the stereo pair stay consistent enough)
+    for i in (2, 5, 9):
+        left[i, : 8 * i] = 60; right[i, : 8 * i] = 60
+    kw = dict(num_disparities=48, block_size=7, max_features=2048)
+    alone = []
+    one = abi.Context(abi.default_params(W, H, max_batch=1, **kw))
+    one.set_calib(seq.P0, seq.P1)
+    for b in range(B):
+        one.set_images(left[b], right[b], left[b + 1], right[b + 1])
+        Rt, info = one.step(strict=False)
+        alone.append((Rt[0].copy(), info[0].n_features, info[0].n_matched, one.disparity16(0).copy(), [m.copy() for m in one.matches(0)]))
+    one.close()
+    assert len({a[1] for a in alone}) > 3
+    ctx = abi.Context(abi.default_params(W, H, max_batch=B, **kw))
+    ctx.set_calib(seq.P0, seq.P1)
+    for mode in ("pairs", "sequence"):
+        if mode == "pairs":
+            ctx.set_images(left[:B], right[:B], left[1:], right[1:])
+        else:
+            ctx.set_sequence(left, right)
+        Rt, info = ctx.step(strict=False)
+        for b in range(B):
+            want_Rt, nf, nm, disp, m = alone[b]
+            assert info[b].n_features == nf and info[b].n_matched == nm, (mode, b)
+            assert np.array_equal(ctx.disparity16(b), disp), (mode, b)
+            g1, g2 = ctx.matches(b)
+            assert np.array_equal(g1, m[0]) and np.array_equal(g2, m[1]), (mode, b)
+            assert np.array_equal(Rt[b], want_Rt), (mode, b)
+    ctx.close()
