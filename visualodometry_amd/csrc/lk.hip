@@ -66,12 +66,22 @@ __global__ __launch_bounds__(256) void level0_scharr_kernel(const uint8_t* i0, c
     const uint8_t* src = (which == 0 ? i0 : which == 1 ? i1 : which == 2 ? i2 : i3) + (size_t)b * fstride;
     const int y = py - pa.border;
     int c[3][PX_N + 2]; // bordered columns px0-1 .. px0+4 of rows py-1, py, py+1
+    const int xl = px0 - 1 - pa.border; // image column of the first of the six
+    if (xl >= 0 && xl + PX_N + 1 < L.w && y >= 1 && y + 1 < L.h) { // nothing to reflect: the common case
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const uint8_t* row = src + (size_t)reflect101(y - 1 + r, L.h) * pitch;
+        for (int r = 0; r < 3; r++) {
+            const uint8_t* row = src + (size_t)(y - 1 + r) * pitch + xl;
 #pragma unroll
-        for (int i = 0; i < PX_N + 2; i++)
-            c[r][i] = row[reflect101(min(px0 - 1 + i, L.w + 2 * pa.border - 1) - pa.border, L.w)];
+            for (int i = 0; i < PX_N + 2; i++) c[r][i] = row[i];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const uint8_t* row = src + (size_t)reflect101(y - 1 + r, L.h) * pitch;
+#pragma unroll
+            for (int i = 0; i < PX_N + 2; i++)
+                c[r][i] = row[reflect101(min(px0 - 1 + i, L.w + 2 * pa.border - 1) - pa.border, L.w)];
+        }
     }
     const unsigned v = (unsigned)c[1][1] | ((unsigned)c[1][2] << 8) | ((unsigned)c[1][3] << 16) | ((unsigned)c[1][4] << 24);
     *reinterpret_cast<unsigned*>(pyr + (size_t)blockIdx.z * pa.pyr_bytes + L.img_off + (size_t)py * L.pitch + px0) = v;
