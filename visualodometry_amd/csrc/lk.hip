@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, (NR == 1 ? VO_LK_MIN_WAVES : 1)) void lk_row_k
                         int w00, w01, w10, w11;
                         bilinear_weights(qx - inx, qy - iny, w00, w01, w10, w11);
                         const int w0 = (w00 & 0xffff) | (w01 << 16), w1 = (w10 & 0xffff) | (w11 << 16);
-                        const uint8_t* J = Jl + (ptrdiff_t)iny * P + inx;
+                        const uint8_t* J = Jl + (iny * P + inx); // a level is far below 2^31 bytes: 32-bit offset arithmetic
                         int pr[NR + 1][NPX];
 #pragma unroll
                         for (int k = 0; k < NR; k++) pixel_pairs<NDW>(J + rowoff[k], pr[k]);

@@ -433,7 +433,9 @@ __global__ __launch_bounds__((CostTile<NP, NCOL_>::THREADS), 4) void cost_vpath_
                 for (int k = 0; k < NP; k++) C[j][k] = C[j - 1][k] + as_v2s(pa[k * 16]) - as_v2s(ps[k * 16]);
             }
         }
-        if (live_d < D) { // a padded disparity range: the cells beyond it get the cost no path prefers (uniform branch)
+        // a padded disparity range: the cells beyond it get the cost no path prefers.  The condition is uniform; reading it
+        // through readfirstlane keeps it a branch (as a select it would cost every row of every launch 4 NP instructions)
+        if (__builtin_amdgcn_readfirstlane(live_d) < D) {
             const v2s dead = splat(dead_cost);
 #pragma unroll
             for (int j = 0; j < NCOL; j++)
