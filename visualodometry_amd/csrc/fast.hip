@@ -6,9 +6,10 @@
 //                       pixels that pass only: the 16 ring pixels are turned into a bright and a dark 16-bit mask,
 //                       "9 contiguous" is a shift-and-AND test, the corner score is the closed form
 //                       max(t, max_arc min(d), max_arc min(-d)) - 1.
-//  fast_count_kernel  : per image row, number of pixels whose score is a strict 3x3 maximum.
-//  fast_write_kernel  : per image row, the sum of the counts of the rows above is the row's offset; wavefront ballot +
-//                       prefix popcount gives every keypoint its rank, so the output order is y-major, x-minor,
+//  fast_count_kernel  : per image row, the pixels whose score is a strict 3x3 maximum: their number, and their flags as
+//                       64-bit ballot words.
+//  fast_write_kernel  : per image row, the sum of the counts of the rows above is the row's offset; a prefix sum of the
+//                       mask words' popcounts gives every keypoint its rank, so the output order is y-major, x-minor,
 //                       identical on every run.
 #include "vo_ctx.h"
 #include <string.h>
@@ -138,28 +139,41 @@ __device__ __forceinline__ bool is_keypoint(const uint8_t* __restrict__ s, int W
     return v > p[-1] && v > p[1] && v > p[-W - 1] && v > p[-W] && v > p[-W + 1] && v > p[W - 1] && v > p[W] && v > p[W + 1];
 }
 
-__global__ __launch_bounds__(256) void fast_count_kernel(const uint8_t* __restrict__ score, int W, int H, int nms, int* __restrict__ row_count)
+// words of 64 keypoint flags per image row: flag i of a row is column 3 + i (the detection domain starts at column 3)
+__host__ __device__ constexpr int fast_mask_words(int W) { return (W - 6 + 63) / 64; }
+
+__global__ __launch_bounds__(256) void fast_count_kernel(const uint8_t* __restrict__ score, int W, int H, int nms, int* __restrict__ row_count,
+                                                         unsigned long long* __restrict__ mask)
 {
     __shared__ int wsum[4];
     const int y = blockIdx.x, b = blockIdx.y;
     const uint8_t* s = score + (size_t)b * H * W;
+    const int MW = fast_mask_words(W);
+    unsigned long long* mrow = mask + ((size_t)b * H + y) * MW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool row_in = y >= 3 && y < H - 3;
     int cnt = 0;
-    if (y >= 3 && y < H - 3)
-        for (int x = 3 + threadIdx.x; x < W - 3; x += 256) cnt += is_keypoint(s, W, x, y, nms);
+    for (int xs = 3, t = 0; xs < W - 3; xs += 256, t++) {
+        const int x = xs + threadIdx.x;
+        const bool k = row_in && x < W - 3 && is_keypoint(s, W, x, y, nms);
+        const unsigned long long m = __ballot(k); // the flags of 64 consecutive columns: one word of the row's mask
+        if (lane == 0 && 4 * t + wave < MW) mrow[4 * t + wave] = m;
+        cnt += k;
+    }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+    if (lane == 0) wsum[wave] = cnt;
     __syncthreads();
     if (threadIdx.x == 0) row_count[b * H + y] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // Per image row: its offset in the output is the number of keypoints in the rows above (summed by the block from the row
-// counts: at most a few thousand small reads), then wavefront ballot + prefix popcount gives every keypoint its rank.
+// counts: at most a few thousand small reads); the first wavefront then turns the row's mask words into keypoints: a
+// prefix sum of the words' popcounts gives every set flag its rank, so the output order is y-major, x-minor.
 // The block of the last row also publishes the total.
-__global__ __launch_bounds__(256) void fast_write_kernel(const uint8_t* __restrict__ score, int W, int H, int nms, int cap,
-                                                         const int* __restrict__ row_count, vo_point2f* __restrict__ feat,
+__global__ __launch_bounds__(256) void fast_write_kernel(int W, int H, int cap, const int* __restrict__ row_count,
+                                                         const unsigned long long* __restrict__ mask, vo_point2f* __restrict__ feat,
                                                          int* __restrict__ n_feat)
 {
-    __shared__ int wcnt[4];
     __shared__ int wsum[4];
     const int y = blockIdx.x, b = blockIdx.y;
     const int mine = row_count[b * H + y];
@@ -172,24 +186,24 @@ __global__ __launch_bounds__(256) void fast_write_kernel(const uint8_t* __restri
     __syncthreads();
     int base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     if (y == H - 1 && threadIdx.x == 0) n_feat[b] = min(base + mine, cap);
-    if (mine == 0) return;
-    const uint8_t* s = score + (size_t)b * H * W;
+    if (mine == 0 || wave != 0) return;
+    const int MW = fast_mask_words(W);
+    const unsigned long long* mrow = mask + ((size_t)b * H + y) * MW;
     vo_point2f* out = feat + (size_t)b * cap;
-    for (int xs = 3; xs < W - 3; xs += 256) {
-        int x = xs + threadIdx.x;
-        bool k = x < W - 3 && is_keypoint(s, W, x, y, nms);
-        unsigned long long m = __ballot(k);
-        if (lane == 0) wcnt[wave] = __popcll(m);
-        __syncthreads();
-        int before = 0;
-        for (int w = 0; w < wave; w++) before += wcnt[w];
-        int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-        if (k) {
-            int rank = base + before + __popcll(m & ((1ull << lane) - 1ull));
-            if (rank < cap) { out[rank].x = (float)x; out[rank].y = (float)y; }
+    for (int w0 = 0; w0 < MW; w0 += 64) {
+        unsigned long long m = w0 + lane < MW ? mrow[w0 + lane] : 0ull;
+        const int pc = __popcll(m);
+        int incl = pc; // inclusive prefix sum over the lanes
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        int rank = base + incl - pc;
+        const int xw = 3 + 64 * (w0 + lane);
+        while (m) {
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (rank < cap) { out[rank].x = (float)(xw + bit); out[rank].y = (float)y; }
+            rank++;
         }
-        base += total;
-        __syncthreads();
+        base += __shfl(incl, 63);
     }
 }
 
@@ -202,9 +216,9 @@ int launch_fast(vo_ctx* c)
     dim3 g1((W + TILE_W - 1) / TILE_W, (H + TILE_H - 1) / TILE_H, n), b1(TILE_W, 4);
     hipLaunchKernelGGL(fast_score_kernel, g1, b1, 0, c->stream, c->img[0], c->pitch, c->fstride, W, H,
                        c->p.fast_threshold, c->p.fast_nms, c->score);
-    hipLaunchKernelGGL(fast_count_kernel, dim3(H, n), dim3(256), 0, c->stream, c->score, W, H, c->p.fast_nms, c->row_count);
-    hipLaunchKernelGGL(fast_write_kernel, dim3(H, n), dim3(256), 0, c->stream, c->score, W, H, c->p.fast_nms,
-                       c->p.max_features, c->row_count, c->feat, c->n_feat);
+    hipLaunchKernelGGL(fast_count_kernel, dim3(H, n), dim3(256), 0, c->stream, c->score, W, H, c->p.fast_nms, c->row_count, c->kp_mask);
+    hipLaunchKernelGGL(fast_write_kernel, dim3(H, n), dim3(256), 0, c->stream, W, H, c->p.max_features, c->row_count, c->kp_mask,
+                       c->feat, c->n_feat);
     VO_HIP(c, hipGetLastError());
     return VO_OK;
 }
@@ -217,7 +231,10 @@ int launch_fast(vo_ctx* c)
 constexpr size_t kNoAllocMaxPixels = (size_t)1 << 21;   // 2 Mi pixels (e.g. 1920 x 1080); KITTI frames are 0.47 Mi
 constexpr int kNoAllocMaxRows = 4096;
 constexpr size_t kNoAllocScoreBytes = kNoAllocMaxPixels;
-constexpr size_t kNoAllocBytes = kNoAllocScoreBytes + (size_t)kNoAllocMaxRows * sizeof(int);
+constexpr size_t kNoAllocCountBytes = (size_t)kNoAllocMaxRows * sizeof(int);
+// keypoint flags: at most ceil(W / 64) words per row, i.e. at most pixels / 64 + rows words of 8 bytes
+constexpr size_t kNoAllocMaskBytes = (kNoAllocMaxPixels / 64 + kNoAllocMaxRows) * 8;
+constexpr size_t kNoAllocBytes = kNoAllocScoreBytes + kNoAllocCountBytes + kNoAllocMaskBytes;
 static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
 
 static std::mutex g_scratch_mu;
@@ -246,15 +263,16 @@ extern "C" int vo_detect_fast_noalloc(const uint8_t* img_dev, int width, int hei
     }
     uint8_t* score = base;
     int* row_count = reinterpret_cast<int*>(base + kNoAllocScoreBytes);
+    unsigned long long* kp_mask = reinterpret_cast<unsigned long long*>(base + kNoAllocScoreBytes + kNoAllocCountBytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     threshold = std::min(std::max(threshold, 0), 255);
     // every word of the scratch that a kernel reads was written by an earlier kernel of this same call (the score kernel
-    // writes all width x height scores, the count kernel all `height` counts), so nothing has to
+    // writes all width x height scores, the count kernel all `height` counts and every mask word of every row), so nothing has to
     // start at zero and what the previous call left behind is never seen
     dim3 g1((width + TILE_W - 1) / TILE_W, (height + TILE_H - 1) / TILE_H, 1), b1(TILE_W, 4);
     hipLaunchKernelGGL(fast_score_kernel, g1, b1, 0, st, img_dev, stride, (size_t)0, width, height, threshold, nms, score);
-    hipLaunchKernelGGL(fast_count_kernel, dim3(height, 1), dim3(256), 0, st, score, width, height, nms, row_count);
-    hipLaunchKernelGGL(fast_write_kernel, dim3(height, 1), dim3(256), 0, st, score, width, height, nms, cap, row_count, out_dev, n_out_dev);
+    hipLaunchKernelGGL(fast_count_kernel, dim3(height, 1), dim3(256), 0, st, score, width, height, nms, row_count, kp_mask);
+    hipLaunchKernelGGL(fast_write_kernel, dim3(height, 1), dim3(256), 0, st, width, height, cap, row_count, kp_mask, out_dev, n_out_dev);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return vo_fail(nullptr, VO_ERR_HIP, "kernel launch: %s", hipGetErrorString(e));
     return VO_OK;

@@ -166,6 +166,7 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     CR(dalloc(&c->depth, B * H * W));
     CR(dalloc(&c->score, B * H * W));
     CR(dalloc(&c->row_count, B * H));
+    CR(dalloc(&c->kp_mask, B * H * (size_t)((W - 6 + 63) / 64)));
     CR(dalloc(&c->n_feat, 3 * B)); // [3][B]: feature, match and object-point counts, fetched with one copy
     c->n_match = c->n_feat + B; c->n_obj = c->n_feat + 2 * B;
     CR(dalloc(&c->feat, B * F));
@@ -198,7 +199,7 @@ extern "C" void vo_destroy(vo_ctx* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->img_own, c->pre, c->cost, c->agg, c->wta, c->ckpt, c->disp_pre, c->disp16, c->disp32, c->depth, c->score,
-                    c->row_count, c->n_feat, c->feat, c->pyr, c->der, c->legs, c->leg_status, c->m1, c->m2,
+                    c->row_count, c->kp_mask, c->n_feat, c->feat, c->pyr, c->der, c->legs, c->leg_status, c->m1, c->m2,
                     c->obj, c->obj_img, c->hyp, c->hyp_count, c->hyp_mask};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->cloud) (void)hipFree(c->cloud);

@@ -72,6 +72,7 @@ struct vo_ctx {
     // ---- FAST ----
     uint8_t* score = nullptr;    // [n][H][W]
     int* row_count = nullptr;    // [n][H]
+    unsigned long long* kp_mask = nullptr; // [n][H][ceil((W - 6) / 64)] keypoint flags of a row, column 3 first
     int* n_feat = nullptr;       // [n]  (device)
     vo_point2f* feat = nullptr;  // [n][max_features]
     std::vector<int> h_nfeat;    // host copy
