@@ -257,11 +257,8 @@ __device__ __forceinline__ void deriv_pairs(const int* __restrict__ p, int (&dx)
     }
 }
 
-#ifndef VO_LK_MIN_WAVES
-#define VO_LK_MIN_WAVES 1
-#endif
 template <int NR, int NDW>
-__global__ __launch_bounds__(256, (NR == 1 ? VO_LK_MIN_WAVES : 1)) void lk_row_kernel(LkArgs a, const uint8_t* __restrict__ pyr, const int16_t* __restrict__ der,
+__global__ __launch_bounds__(256) void lk_row_kernel(LkArgs a, const uint8_t* __restrict__ pyr, const int16_t* __restrict__ der,
                                                      const vo_point2f* __restrict__ feat, const int* __restrict__ n_feat,
                                                      vo_point2f* __restrict__ legs, uint8_t* __restrict__ leg_status)
 {

@@ -519,14 +519,8 @@ __global__ __launch_bounds__(256) void hpath_ckpt_kernel(const int16_t* __restri
 }
 
 // 7 and 8 pairs per lane come out just over 256 registers, which is one wavefront per SIMD; held to 256, two fit
-#ifndef VO_HP_WIDE_MIN_WAVES
-#define VO_HP_WIDE_MIN_WAVES 2
-#endif
-#ifndef VO_HP_NP3_MIN_WAVES
-#define VO_HP_NP3_MIN_WAVES 1
-#endif
 template <int NP>
-__global__ __launch_bounds__(64, (NP >= 7 ? VO_HP_WIDE_MIN_WAVES : NP == 3 ? VO_HP_NP3_MIN_WAVES : 1)) void hpath_resolve_kernel(const int16_t* __restrict__ cost, const int16_t* __restrict__ ltop, int width1,
+__global__ __launch_bounds__(64, (NP >= 7 ? 2 : 1)) void hpath_resolve_kernel(const int16_t* __restrict__ cost, const int16_t* __restrict__ ltop, int width1,
                                                             int Dp, int W, int H, int srows, StripeInfo si, int stripe_sz, int P1, int P2,
                                                             int tie_lanes, int nseg, const int* __restrict__ ckpt, int32_t* __restrict__ wta, int D)
 {

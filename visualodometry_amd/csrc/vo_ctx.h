@@ -143,10 +143,7 @@ inline size_t vo_cost_tiles(const vo_ctx* c)
 // so wide disparity ranges (more cells per lane) get shorter segments
 // pixels per row of the prefiltered images: the width rounded up to the 4 pixels a prefilter thread writes
 inline int vo_pre_pitch(const vo_ctx* c) { return (c->W + 3) & ~3; }
-#ifndef VO_HP_SEG_NARROW
-#define VO_HP_SEG_NARROW 16
-#endif
-constexpr int vo_hpath_seg(int pairs_per_lane) { return pairs_per_lane <= 4 ? VO_HP_SEG_NARROW : 8; }
+constexpr int vo_hpath_seg(int pairs_per_lane) { return pairs_per_lane <= 4 ? 16 : 8; }
 inline int vo_hpath_segments(const vo_ctx* c) { const int seg = vo_hpath_seg(c->Dp / 32); return (c->width1 + seg - 1) / seg; }
 
 // ---- launchers (each enqueues on c->stream, returns a vo_status) ----
