@@ -277,6 +277,7 @@ def parse_args(argv):
     ap.add_argument("--upload", action="store_true",
                     help="re-upload the batch's images from host memory before every step of the timed region (PCIe-inclusive rate; "
                          "the headline value is measured without it, inputs resident in HBM)")
+    ap.add_argument("--pageable-upload", action="store_true", help="the upload-inclusive pass copies from pageable instead of page-locked host memory")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the second, upload-inclusive timed pass (config.value_with_upload)")
     ap.add_argument("--latency", action="store_true",
                     help="also time one frame pair alone (batch of 1) after the run; off by default so that a kernel profile "
@@ -556,10 +557,15 @@ def main(argv=None):
             timing[k] = (a[0] + v[0], a[1] + v[1])
 
     # ---- outside the timed region
-    # the same K steps with every window re-uploaded from (pageable) host memory first: the PCIe-inclusive rate
+    # the same K steps with every window re-uploaded from host memory first: the PCIe-inclusive rate
+    # (page-locked host buffers, as a capture pipeline would hand them over; --pageable-upload for ordinary memory)
     value_with_upload = None
     if not strong and not args.upload and not args.no_upload_leg and not stub:
-        host_left, host_right = left.cpu().numpy(), right.cpu().numpy()
+        if args.pageable_upload:
+            host_left, host_right = left.cpu().numpy(), right.cpu().numpy()
+        else:
+            pinned = (left.cpu().pin_memory(), right.cpu().pin_memory())   # kept alive until the end of main()
+            host_left, host_right = pinned[0].numpy(), pinned[1].numpy()
         run_steps(min(3, args.steps), upload=True)
         barrier(); dev_sync()
         tu = time.perf_counter()
