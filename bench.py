@@ -322,7 +322,11 @@ def main(argv=None):
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     # host threads: one pool per process, sized to this rank's share of the node's cores
-    cpu_share = max(1, min(16, (os.cpu_count() or 1) // max(local_world, 1)))
+    try:
+        ncpu = len(os.sched_getaffinity(0))   # the cores this process may run on, where the platform tells
+    except (AttributeError, OSError):
+        ncpu = os.cpu_count() or 1
+    cpu_share = max(1, min(16, ncpu // max(local_world, 1)))
     if args.host_threads <= 0:
         args.host_threads = cpu_share
 
