@@ -305,6 +305,28 @@ def step(lt1, rt1, lt2, rt2, params, P0, P1, pose):
     return Rt, info
 
 
+def step_ex(lt1, rt1, lt2, rt2, params, P0, P1, pose):
+    """orc_step_ex: one main-loop iteration that also returns the stage outputs.
+    Returns (Rt, info, disp16, fast keypoints, matched T1 points, matched T2 points); pose is updated in place."""
+    imgs = [np.ascontiguousarray(i, dtype=np.uint8) for i in (lt1, rt1, lt2, rt2)]
+    h, w = imgs[0].shape
+    P0 = np.ascontiguousarray(P0, dtype=np.float64)
+    P1 = np.ascontiguousarray(P1, dtype=np.float64)
+    Rt = np.zeros((4, 4))
+    info = StepInfo()
+    d16 = np.zeros((h, w), dtype=np.int16)
+    cap = w * h // 4
+    kp = np.zeros((cap, 2), dtype=np.float32)
+    t1 = np.zeros((cap, 2), dtype=np.float32)
+    t2 = np.zeros((cap, 2), dtype=np.float32)
+    rc = lib().orc_step_ex(*[_p(i, C.c_uint8) for i in imgs], C.byref(params), _p(P0, C.c_double), _p(P1, C.c_double),
+                           _p(pose, C.c_double), _p(Rt, C.c_double), C.byref(info), _p(d16, C.c_int16), _p(kp, Point2f),
+                           _p(t1, Point2f), _p(t2, Point2f))
+    if rc != 0:
+        raise RuntimeError("orc_step_ex failed")
+    return Rt, info, d16, kp[:info.n_fast].copy(), t1[:info.n_matched].copy(), t2[:info.n_matched].copy()
+
+
 def trajectory_rmse(est, gt):
     est = np.ascontiguousarray(est, dtype=np.float64)
     gt = np.ascontiguousarray(gt, dtype=np.float64)

@@ -80,9 +80,10 @@ extern "C" int orc_estimate_motion(const orc_point2f* t1, const orc_point2f* t2,
     return ok ? k : -k - 1;
 }
 
-extern "C" int orc_step(const uint8_t* lt1, const uint8_t* rt1, const uint8_t* lt2, const uint8_t* rt2,
-                        const orc_params* p, const double* P0, const double* P1, double pose[16],
-                        double Rt_out[16], orc_step_info* info)
+extern "C" int orc_step_ex(const uint8_t* lt1, const uint8_t* rt1, const uint8_t* lt2, const uint8_t* rt2,
+                           const orc_params* p, const double* P0, const double* P1, double pose[16],
+                           double Rt_out[16], orc_step_info* info, int16_t* disp16_out, orc_point2f* fast_out,
+                           orc_point2f* match_t1_out, orc_point2f* match_t2_out)
 {
     using clk = std::chrono::steady_clock;
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -91,6 +92,7 @@ extern "C" int orc_step(const uint8_t* lt1, const uint8_t* rt1, const uint8_t* l
     auto t0 = clk::now();
     std::vector<int16_t> d16((size_t)W * H);
     if (orc_sgbm3way(lt1, rt1, p, d16.data(), nullptr) != 0) return -1;
+    if (disp16_out) memcpy(disp16_out, d16.data(), sizeof(int16_t) * (size_t)W * H);
     std::vector<float> disp((size_t)W * H);
     orc_disp_to_float(d16.data(), W * H, disp.data());
     std::vector<double> depth((size_t)W * H);
@@ -101,8 +103,11 @@ extern "C" int orc_step(const uint8_t* lt1, const uint8_t* rt1, const uint8_t* l
     std::vector<orc_point2f> f1(cap), f2(cap);
     int n = orc_fast(lt1, W, H, W, p->fast_threshold, p->fast_nms, f1.data(), nullptr, cap, nullptr);
     if (n > cap) n = cap;
+    if (fast_out) memcpy(fast_out, f1.data(), sizeof(orc_point2f) * (size_t)n);
     auto t2 = clk::now();
     int m = orc_match_klt(lt1, rt1, lt2, rt2, p, f1.data(), n, f2.data(), nullptr, nullptr);
+    if (match_t1_out) memcpy(match_t1_out, f1.data(), sizeof(orc_point2f) * (size_t)m);
+    if (match_t2_out) memcpy(match_t2_out, f2.data(), sizeof(orc_point2f) * (size_t)m);
     auto t3 = clk::now();
     double tp[3];
     int k = orc_estimate_motion(f1.data(), f2.data(), m, depth.data(), p, P0, pose, Rt_out, tp, &li.pnp);
@@ -111,6 +116,13 @@ extern "C" int orc_step(const uint8_t* lt1, const uint8_t* rt1, const uint8_t* l
     li.ms_disparity = ms(t0, t1); li.ms_fast = ms(t1, t2); li.ms_klt = ms(t2, t3); li.ms_motion = ms(t3, t4);
     if (info) *info = li;
     return 0;
+}
+
+extern "C" int orc_step(const uint8_t* lt1, const uint8_t* rt1, const uint8_t* lt2, const uint8_t* rt2,
+                        const orc_params* p, const double* P0, const double* P1, double pose[16],
+                        double Rt_out[16], orc_step_info* info)
+{
+    return orc_step_ex(lt1, rt1, lt2, rt2, p, P0, P1, pose, Rt_out, info, nullptr, nullptr, nullptr, nullptr);
 }
 
 extern "C" float orc_trajectory_rmse(const double* est, const double* gt, int n)

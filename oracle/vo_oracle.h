@@ -162,6 +162,13 @@ int orc_step(const uint8_t* lt1, const uint8_t* rt1, const uint8_t* lt2, const u
              const orc_params* p, const double* P0, const double* P1, double pose_inout[16],
              double Rt_out[16], orc_step_info* info);
 
+/* the same iteration, also handing out what its stages produced (each pointer nullable): the s16 disparity map (W*H), the FAST
+ * list (W*H/4 points at most; info->n_fast of them written) and the circular-matching survivors (info->n_matched pairs) */
+int orc_step_ex(const uint8_t* lt1, const uint8_t* rt1, const uint8_t* lt2, const uint8_t* rt2,
+                const orc_params* p, const double* P0, const double* P1, double pose_inout[16],
+                double Rt_out[16], orc_step_info* info, int16_t* disp16_out, orc_point2f* fast_out,
+                orc_point2f* match_t1_out, orc_point2f* match_t2_out);
+
 /* RMSE of Source/VOClass.cpp:627-649 (float accumulator as in the reference) */
 float orc_trajectory_rmse(const double* est /*n*3*/, const double* gt /*n*3*/, int n);
 

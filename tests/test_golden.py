@@ -49,6 +49,34 @@ def test_oracle_reproduces_hard_sgbm_and_rng():
         assert np.array_equal(ob.rng_subsets(int(c), 100), r[c])
 
 
+def test_oracle_reproduces_kitti200_steps():
+    """full-length fixture (tests/golden/make_kitti200.py): the oracle still gives its hashes, counts and poses on the steps
+    tried here (the first, and one from the middle), and the renderer still gives the frames it was made from"""
+    from visualodometry_amd import synth
+    from fullsize_util import h64
+    g = load("kitti200")
+    W, H, D, seed = (int(g[k]) for k in ("width", "height", "num_disparities", "seed"))
+    seq = synth.Sequence(seed=seed, width=W, height=H)
+    p = ob.default_params(W, H, num_disparities=D)
+    ob.set_threads(min(8, os.cpu_count() or 1))
+    for i in (0, 117):
+        a, b = seq.frame(i), seq.frame(i + 1)
+        assert [h64(a[0]), h64(a[1])] == [int(v) for v in g["frame_hash"][i]]
+        pose = np.eye(4)
+        Rt, info, d16, kp, t1, t2 = ob.step_ex(a[0], a[1], b[0], b[1], p, seq.P0, seq.P1, pose)
+        assert h64(d16) == int(g["disp_hash"][i]) and h64(kp) == int(g["fast_hash"][i])
+        assert h64(np.concatenate([t1, t2])) == int(g["match_hash"][i])
+        assert (info.n_fast, info.n_matched, info.n_obj) == (int(g["n_fast"][i]), int(g["n_matched"][i]), int(g["n_obj"][i]))
+        assert (info.pnp.iters_run, info.pnp.best_inliers) == (int(g["pnp_iters"][i]), int(g["pnp_inliers"][i]))
+        assert np.allclose(Rt, g["Rt"][i], atol=1e-12)
+    ob.set_threads(1)
+    # the integrated trajectory of the fixture is the ordered product of its own relative poses (Source/VOClass.cpp:587)
+    pose = np.eye(4)
+    for i in range(len(g["Rt"])):
+        pose = pose @ ob.inv4x4(g["Rt"][i])
+        assert np.allclose(pose[:3, 3], g["trajectory"][i + 1], atol=1e-9)
+
+
 # ------------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", STEREO)
