@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the stereo front-end hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--batch B] [--workload kitti|4k|kitti11]
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--workload kitti|4k|kitti11|dense]
 
 One "step" = one pass of the whole per-frame hot path (disparity, FAST, circular KLT, triangulation,
 PnP-RANSAC; one iteration of the reference's main loop, Source/main.cpp:36-60) over a batch of B independent
@@ -10,6 +10,9 @@ synthetic stereo frame pairs that are already resident in HBM.
 Workloads
   kitti, 4k   weak scaling: every rank streams its own rendered sequence (seed 1000 + rank) through K steps of B
               consecutive frame pairs; no pair repeats inside a batch or between the batches in flight.
+  dense       the dense-tracking configuration at KITTI shape: 20 000 corners per frame (threshold 10, no suppression, the first
+              20 000 in row-major order), 21x21 tracking window on a 4-level pyramid, 1 024 RANSAC hypotheses solved and scored
+              per frame (one scoring launch per batch).
   kitti11     strong scaling, the 11 KITTI 00-10-shaped sequences (4541 ... 1201 frames): whole sequences are dealt
               to ranks longest-first (sequence.assign_sequences), or with --chunked the steps of all sequences are
               cut into equal contiguous ranges (sequence.assign_chunks); value = all steps / slowest rank's time.
@@ -51,7 +54,11 @@ def workload_shape(name, args):
     if name in ("kitti", "kitti11"):
         s = dict(width=1241, height=376, num_disparities=96, lk_win=15, max_features=16384)
     elif name == "4k":
-        s = dict(width=3840, height=2160, num_disparities=256, lk_win=15, max_features=65536)
+        # the pixel-matched 4K scene has the corner density per pixel of the KITTI-shape one: about 77 000 corners a frame
+        s = dict(width=3840, height=2160, num_disparities=256, lk_win=15, max_features=98304)
+    elif name == "dense":
+        s = dict(width=1241, height=376, num_disparities=96, lk_win=21, max_features=20000,
+                 extra=dict(fast_threshold=10, fast_nms=0, ransac_iters=1024, ransac_chunk=1024))
     else:
         raise ValueError(name)
     if args.width:
@@ -109,20 +116,28 @@ def frame_bytes(W, H, D, n_feat=4000):
 
 
 # ------------------------------------------------------------------ rendering (host, before any GPU use)
+def scene_kwargs(workload, W):
+    """The synthetic scene of a workload: the 4K one keeps the per-pixel statistics of the KITTI-shape scene (texture
+    wavelengths, baseline, step and yaw scaled by 1241 / width), so that its tracking and pose load is representative:
+    85 % of the corners close the matching circle, as at KITTI shape, where the unscaled scene kept a third."""
+    from visualodometry_amd import synth
+    return synth.pixel_matched_scene(W) if workload == "4k" else {}
+
+
 def _render_one(job):
     from visualodometry_amd import synth
-    seed, W, H, i = job
-    return synth.Sequence(seed=seed, width=W, height=H).frame(i)
+    seed, W, H, i, kw = job
+    return synth.Sequence(seed=seed, width=W, height=H, **kw).frame(i)
 
 
-def render_frames(seed, W, H, count, workers, cache_dir=""):
+def render_frames(seed, W, H, count, workers, cache_dir="", scene=None):
     """`count` consecutive stereo frames of the synthetic sequence `seed`, rendered on `workers` host processes.
     cache_dir: keep / reuse the rendered frames there (profiler passes, where the process must not fork)."""
-    cache = os.path.join(cache_dir, "frames_s%d_%dx%d_n%d.npy" % (seed, W, H, count)) if cache_dir else ""
+    cache = os.path.join(cache_dir, "frames_s%d_%dx%d_n%d%s.npy" % (seed, W, H, count, "_pm" if scene else "")) if cache_dir else ""
     if cache and os.path.exists(cache):
         a = np.load(cache)
         return [(a[i, 0], a[i, 1]) for i in range(count)]
-    jobs = [(seed, W, H, i) for i in range(count)]
+    jobs = [(seed, W, H, i, scene or {}) for i in range(count)]
     if workers <= 1 or count <= 2:
         out = [_render_one(j) for j in jobs]
     else:
@@ -133,6 +148,23 @@ def render_frames(seed, W, H, count, workers, cache_dir=""):
         os.makedirs(cache_dir, exist_ok=True)
         np.save(cache, np.stack([np.stack(f) for f in out]))
     return out
+
+
+class stdout_to_stderr:
+    """File descriptor 1 points to stderr inside the block: a communication library that prints a version banner from C
+    code when its communicator comes up must not put it in front of the one JSON line that stdout carries."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
 
 
 # ------------------------------------------------------------------ self-launch of N ranks
@@ -231,22 +263,36 @@ def cpu_baseline(frames, seq, shape, sample_pairs):
     from oracle import binding as ob
     threads = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))))
     ob.set_threads(threads)
-    p = ob.default_params(shape["width"], shape["height"], num_disparities=shape["num_disparities"], lk_win=shape["lk_win"])
+    extra = {k: v for k, v in shape.get("extra", {}).items() if k != "ransac_chunk"}   # the port has no hypothesis batching
+    p = ob.default_params(shape["width"], shape["height"], num_disparities=shape["num_disparities"], lk_win=shape["lk_win"], **extra)
+    cap = shape["max_features"] if "extra" in shape else None
     pose = np.eye(4)
-    npairs = sample_pairs
     nd = len(frames) - 1
+
+    def one(i):
+        a, b = frames[i], frames[i + 1]
+        if cap is None:
+            ob.step(a[0], a[1], b[0], b[1], p, seq.P0, seq.P1, pose)
+            return
+        # a capped corner list (the dense-tracking configuration keeps the first `cap` corners): the same stages one by one
+        d32 = ob.disp_to_float(ob.sgbm(a[0], a[1], p))
+        depth = ob.depth_map(d32, seq.P0[0, 0], seq.P1[0, 3] / (-seq.P0[0, 0]))
+        kp = ob.fast(a[0], p.fast_threshold, bool(p.fast_nms), cap=cap)
+        t1, t2 = ob.match_klt(a[0], a[1], b[0], b[1], kp, p)
+        obj, _, i2 = ob.triangulate(t1, t2, depth, seq.P0)
+        ob.solve_pnp_ransac(obj, i2, seq.P0, p)
+
+    npairs = sample_pairs
     t0 = time.perf_counter()
     for k in range(npairs):
-        i = k % nd
-        ob.step(frames[i][0], frames[i][1], frames[i + 1][0], frames[i + 1][1], p, seq.P0, seq.P1, pose)
+        one(k % nd)
     dt = time.perf_counter() - t0
     # the same port on one thread, on a smaller sample
     ob.set_threads(1)
     n1 = max(1, min(3, npairs))
     t1 = time.perf_counter()
     for k in range(n1):
-        i = k % nd
-        ob.step(frames[i][0], frames[i][1], frames[i + 1][0], frames[i + 1][1], p, seq.P0, seq.P1, pose)
+        one(k % nd)
     dt1 = time.perf_counter() - t1
     ob.set_threads(threads)
     return {"value": npairs / dt, "unit": "stereo frames/s", "cores": threads, "kind": "port",
@@ -262,13 +308,14 @@ def parse_args(argv):
                     help="timed steps (default 300, about 2.3 s at KITTI shape: the fill and drain of the pipeline are 3 %% of 50 steps)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="frame pairs per step (default: 42 at KITTI shape, 8 at 4K)")
-    ap.add_argument("--workload", default="kitti", choices=["kitti", "4k", "kitti11"])
+    ap.add_argument("--workload", default="kitti", choices=["kitti", "4k", "kitti11", "dense"])
     ap.add_argument("--frames", type=int, default=0,
-                    help="consecutive frames rendered per rank and kept in HBM (default: one window of `batch` pairs per batch in "
-                         "flight, plus one; 200 = the whole sequence of the single-GPU configuration)")
+                    help="consecutive frames rendered per rank and kept in HBM (default: 200 at KITTI shape, the whole sequence of "
+                         "the single-GPU configuration; otherwise one window of `batch` pairs per batch in flight, plus one)")
     ap.add_argument("--chunked", action="store_true", help="kitti11: contiguous step ranges per rank instead of whole sequences")
     ap.add_argument("--scale", type=float, default=1.0, help="kitti11: scale every sequence length (rehearsals, tests)")
-    ap.add_argument("--cpu-pairs", type=int, default=12)
+    ap.add_argument("--cpu-pairs", type=int, default=0,
+                    help="frame pairs of the CPU baseline's sample (default: 48 at KITTI shape, about 10 s on 16 threads; 1 at 4K)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--inflight", type=int, default=0,
@@ -279,9 +326,13 @@ def parse_args(argv):
                          "the headline value is measured without it, inputs resident in HBM)")
     ap.add_argument("--pageable-upload", action="store_true", help="the upload-inclusive pass copies from pageable instead of page-locked host memory")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the second, upload-inclusive timed pass (config.value_with_upload)")
-    ap.add_argument("--latency", action="store_true",
-                    help="also time one frame pair alone (batch of 1) after the run; off by default so that a kernel profile "
-                         "of the default command holds launches of one batch size only")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the pass that times one frame pair alone (batch of 1, 12 steps) after the run: use it for a kernel "
+                         "profile that should hold launches of one batch size only")
+    ap.add_argument("--latency", action="store_true", help="(kept for old command lines: the latency pass is on by default)")
+    ap.add_argument("--no-collective", action="store_true",
+                    help="single rank: do not create the one-rank RCCL communicator and skip the result gathers (by default they run "
+                         "on device tensors exactly as with N ranks, after the timed steps)")
     ap.add_argument("--mode", default="sequence", choices=["pairs", "sequence"],
                     help="sequence (default): a step's window is B + 1 consecutive frames of the rank's sequence, handed over as such; "
                          "every frame is uploaded and pyramided once and serves as T2 of one pair and T1 of the next (same results). "
@@ -314,8 +365,10 @@ def main(argv=None):
         # take more solver work), and a fourth batch covers it.
         args.inflight = 4 if args.workload == "kitti11" else 3
     if args.inflight > 3:
-        # a process gets 4 hardware queues by default; with more streams than queues the batches serialise behind each other
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(2 * args.inflight))
+        # a process gets 4 hardware queues by default; with more streams than queues the batches serialise behind each other.
+        # (Under a profiler that initialises the runtime before main() the variable has to be exported in the shell instead.)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(32, 2 * args.inflight)))
+        log("[bench] GPU_MAX_HW_QUEUES=%s for %d batches in flight" % (os.environ["GPU_MAX_HW_QUEUES"], args.inflight))
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -339,11 +392,12 @@ def main(argv=None):
     # ---- input: rendered on the host before the GPU is touched (the worker pool is forked)
     from visualodometry_amd import synth
     seq_seed = 1000 if strong else 1000 + rank
-    seq = synth.Sequence(seed=seq_seed, width=W, height=H)
-    nframes = args.frames if args.frames > 0 else nctx * B + 1
+    scene = scene_kwargs(args.workload, W)
+    seq = synth.Sequence(seed=seq_seed, width=W, height=H, **scene)
+    nframes = args.frames if args.frames > 0 else (200 if args.workload in ("kitti", "dense") else nctx * B + 1)
     nframes = max(nframes, B + 1)
     t0 = time.perf_counter()
-    frames = render_frames(seq_seed, W, H, nframes, cpu_share, args.frame_cache)
+    frames = render_frames(seq_seed, W, H, nframes, cpu_share, args.frame_cache, scene)
     log("[rank %d] rendered %d synthetic %dx%d stereo frames in %.1f s on %d host processes" % (rank, nframes, W, H, time.perf_counter() - t0, cpu_share))
 
     import torch
@@ -358,14 +412,20 @@ def main(argv=None):
             raise SystemExit("bench.py: %d ranks on this node but %d GPUs (use --rehearse to share GPUs in a plumbing rehearsal)" % (local_world, ndev))
         device_index = local_rank % ndev
     backend = "gloo" if (stub or args.rehearse) else "nccl"
-    if world > 1:
+    # A single rank still creates its (one-rank) RCCL communicator and runs the result gathers on device tensors, the same
+    # code path as N ranks: the collective of this workload is then exercised by every run, not only on a multi-GPU node.
+    collective = world > 1 or not (stub or args.no_collective)
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
         # RCCL ("nccl") is the backend of a real run; gloo only for rehearsing the multi-rank flow
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        with stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
     if stub:
         dev = torch.device("cpu")
     else:
@@ -385,7 +445,7 @@ def main(argv=None):
         ctxs = [StubContext(W, H, B) for _ in range(nctx)]
     else:
         p = abi.default_params(W, H, max_batch=B, num_disparities=D, lk_win=shape["lk_win"], max_features=shape["max_features"],
-                               host_threads=args.host_threads)
+                               host_threads=args.host_threads, **shape.get("extra", {}))
         ctxs = [abi.Context(p, device_index) for _ in range(nctx)]
     for c in ctxs:
         c.set_calib(seq.P0, seq.P1)
@@ -399,11 +459,17 @@ def main(argv=None):
             c.set_sequence_device(n, lptr, rptr, W, FS, keep=(left, right))
 
     # ---- weak-scaling workload: K steps over windows of the rank's own sequence
-    nwin = (nframes - 1) // B   # disjoint windows of B pairs; batches in flight at the same time use different ones
+    # windows of B consecutive pairs that together cover every pair of the rendered sequence: disjoint ones from the start,
+    # plus one that ends at the last frame (it overlaps its predecessor when B does not divide the pair count).  Batches in
+    # flight at the same time work on different windows.
+    win_start = list(range(0, nframes - B, B))
+    if (nframes - 1) % B:
+        win_start.append(nframes - 1 - B)
+    nwin = len(win_start)
     host_left = host_right = None
 
     def submit_window(c, w, upload):
-        f0 = (w % nwin) * B
+        f0 = win_start[w % nwin]
         if upload:   # host -> device copy of the window's frames, then the step
             if args.mode == "pairs":
                 c.set_images(host_left[f0:f0 + B], host_right[f0:f0 + B], host_left[f0 + 1:f0 + B + 1], host_right[f0 + 1:f0 + B + 1])
@@ -487,6 +553,18 @@ def main(argv=None):
         if world > 1:
             dist.barrier()
 
+    def gather_results(Rt, lastc):
+        """the only collective of the weak-scaling workloads: the per-frame relative poses of every rank, and the point clouds
+        (triangulated points) of the last batch as fixed-size padded buffers (result gather, RCCL over xGMI)"""
+        poses = torch.from_numpy(np.ascontiguousarray(Rt)).to(cdev)
+        gathered = [torch.empty_like(poses) for _ in range(world)]
+        dist.all_gather(gathered, poses)
+        out = {r: g.cpu().numpy() for r, g in enumerate(gathered)}
+        clouds = vseq.gather_point_clouds([lastc.object_points(b)[0] for b in range(B)], cap=shape["max_features"])
+        assert len(clouds) == world
+        dev_sync()
+        return out, clouds
+
     # ---- warm-up
     if args.warmup > 0:
         if strong:
@@ -499,18 +577,20 @@ def main(argv=None):
 
     # ---- timed region
     cdev = dev if (world == 1 or backend == "nccl") else torch.device("cpu")
-    if world > 1:
+    if collective:
         # the collectives of the timed region once beforehand, with the same shapes and empty payloads: a communicator sets up
         # its channels and loads its kernels on first use, which is start-up cost, not part of a step
-        if strong:
-            vseq.gather_trajectories({}, len(lengths), max(lengths) - 1)
-        else:
-            z = torch.zeros((B, 4, 4), dtype=torch.float64, device=cdev)
-            dist.all_gather([torch.empty_like(z) for _ in range(world)], z)
-            vseq.gather_point_clouds([np.zeros((0, 3), dtype=np.float32)] * B, cap=shape["max_features"])
-        z1 = torch.zeros(1, dtype=torch.float64, device=cdev)
-        dist.all_reduce(z1, op=dist.ReduceOp.MAX)
-        dist.all_gather([torch.empty_like(z1) for _ in range(world)], z1)
+        with stdout_to_stderr():
+            if strong:
+                vseq.gather_trajectories({}, len(lengths), max(lengths) - 1)
+            else:
+                z = torch.zeros((B, 4, 4), dtype=torch.float64, device=cdev)
+                dist.all_gather([torch.empty_like(z) for _ in range(world)], z)
+                vseq.gather_point_clouds([np.zeros((0, 3), dtype=np.float32)] * B, cap=shape["max_features"])
+            z1 = torch.zeros(1, dtype=torch.float64, device=cdev)
+            dist.all_reduce(z1, op=dist.ReduceOp.MAX)
+            dist.all_gather([torch.empty_like(z1) for _ in range(world)], z1)
+            dev_sync()
     if args.upload:
         host_left, host_right = left.cpu().numpy(), right.cpu().numpy()
     barrier(); dev_sync()
@@ -539,17 +619,9 @@ def main(argv=None):
             c.synchronize()
         dev_sync()
         t_compute = time.perf_counter() - t0
-        # the only collective: gather the per-frame relative poses of every rank (result gather, RCCL over xGMI)
-        poses = torch.from_numpy(np.ascontiguousarray(Rt)).to(cdev)
-        if world > 1:
-            gathered = [torch.empty_like(poses) for _ in range(world)]
-            dist.all_gather(gathered, poses)
-            gathered_poses = {r: g.cpu().numpy() for r, g in enumerate(gathered)}
-            # ... and the point clouds (triangulated points) of the last batch, as fixed-size padded buffers
-            lastc = ctxs[(args.steps - 1) % nctx]
-            clouds = vseq.gather_point_clouds([lastc.object_points(b)[0] for b in range(B)], cap=shape["max_features"])
-            assert len(clouds) == world
-            dev_sync()
+        clouds = None
+        if collective:
+            gathered_poses, clouds = gather_results(Rt, ctxs[(args.steps - 1) % nctx])
         else:
             gathered_poses = {0: np.asarray(Rt)}
         my_steps = args.steps * B
@@ -565,6 +637,11 @@ def main(argv=None):
         tcs = [torch.empty_like(tc) for _ in range(world)]
         dist.all_gather(tcs, tc)
         t_all = [float(t.item()) for t in tcs]
+
+    if collective and world == 1 and not strong and not stub:   # one rank: the gather must hand back exactly what went in
+        assert np.array_equal(gathered_poses[0], np.asarray(Rt)), "one-rank pose gather changed the poses"
+        want = [ctxs[(args.steps - 1) % nctx].object_points(b)[0] for b in range(B)]
+        assert all(np.array_equal(a, b_) for a, b_ in zip(clouds[0], want)), "one-rank point-cloud gather changed the points"
 
     timing = {}
     for c in ctxs:
@@ -606,7 +683,7 @@ def main(argv=None):
         isolated = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in ctx.timing().items()}
     # latency of one frame pair alone (batch of 1, one stream, nothing else in flight)
     latency_ms = None
-    if args.latency and not stub:
+    if not args.no_latency and not stub:
         set_window(ctx, left.data_ptr(), right.data_ptr(), 1)
         for _ in range(2):
             ctx.step()
@@ -636,14 +713,17 @@ def main(argv=None):
         dom = max(hbm_kernels, key=lambda k: excl.get(k, 0.0))
         achieved = kb[dom] / (excl[dom] * 1e-3) / 1e9 if excl.get(dom, 0) > 0 else 0.0
         traffic = None
+        traffic_per_frame = None   # HBM bytes of ALL the path's kernels per frame, from the same counter passes
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
+        if os.path.exists(tf) and args.workload in ("kitti", "kitti11", "4k"):
             try:
                 tj = json.load(open(tf))
                 wk = "4k" if args.workload == "4k" else "kitti"
+                cb = tj.get(wk + "_batch", 8 if wk == "4k" else 16)   # the batch size the counters were collected at
                 traffic = tj.get(wk, {}).get(dom)
-                if traffic is not None:  # counters were collected at the batch size recorded beside them: bytes scale with frames
-                    traffic = traffic * B / tj.get(wk + "_batch", 8 if wk == "4k" else 16)
+                if traffic is not None:  # bytes scale with the frames of a launch
+                    traffic = traffic * B / cb
+                traffic_per_frame = sum(v for v in tj.get(wk, {}).values() if isinstance(v, (int, float))) / cb
             except Exception:
                 traffic = None
 
@@ -672,7 +752,8 @@ def main(argv=None):
                               "(SGBM-3way + FAST + circular KLT + triangulation + PnP-RANSAC)" % (args.workload, W, H, D, B),
                   "batch": B, "batches_in_flight": nctx, "input_mode": args.mode,
                   "inputs": "uploaded from host memory every step" if args.upload else "resident in HBM",
-                  "distinct_frames_per_rank": nframes, "host_threads_per_rank": args.host_threads,
+                  "distinct_frames_per_rank": nframes, "windows_per_rank": nwin, "host_threads_per_rank": args.host_threads,
+                  "result_gather": ("executed (%s, %d rank%s)" % ("RCCL" if backend == "nccl" else "gloo", world, "" if world == 1 else "s")) if collective else "skipped",
                   "sharding": ("11 KITTI 00-10-shaped sequences (%d steps), %s; relative poses all-gathered once (%s)" %
                                (total_pairs, "contiguous step ranges per rank" if args.chunked else "whole sequences per rank, longest first",
                                 "RCCL" if backend == "nccl" else "gloo")) if strong else
@@ -707,7 +788,12 @@ def main(argv=None):
                 "kernel_choice": "longest launch among the kernels bound by HBM; the tracker (lk) is bound by vector-instruction issue, "
                                  "see valu_issue",
                 # the whole path against the same roof: algorithmic bytes per frame x frames/s of one GPU
-                "whole_path": {"algorithmic_GBs": whole_gbs, "frac": whole_gbs / HBM_PEAK_GBS},
+                # traffic_inflation: measured HBM bytes of all the path's kernels per frame (FETCH_SIZE x 2 + WRITE_SIZE counter
+                # passes, profiles/traffic.json) / algorithmic bytes per frame
+                "whole_path": {"algorithmic_GBs": whole_gbs, "frac": whole_gbs / HBM_PEAK_GBS,
+                               "algorithmic_bytes_per_frame": frame_bytes(W, H, D),
+                               "hbm_bytes_per_frame_measured": traffic_per_frame,
+                               "traffic_inflation": (traffic_per_frame / frame_bytes(W, H, D)) if traffic_per_frame else None},
                 # what plain streaming kernels reach on this GPU (tools/micro/hbm_rate.hip, measured once)
                 "streaming_GBs_measured": {"read": 6290, "write": 3890, "copy": 4450, "1_read_4_writes": 4440},
                 "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": excl.get(dom, 0.0),
@@ -719,11 +805,13 @@ def main(argv=None):
                                    "avg_launch_ms": round(excl.get(k, 0.0), 4), "frac": frac(excl, k),
                                    "avg_launch_ms_timed_region": round(stage_ms.get(k, 0.0), 4)} for k in kb}}
         if not args.no_cpu and world == 1 and not stub:   # the CPU baseline is a single-GPU-run item
-            out["cpu_baseline"] = cpu_baseline(frames, seq, shape, args.cpu_pairs)
+            out["cpu_baseline"] = cpu_baseline(frames, seq, shape, args.cpu_pairs if args.cpu_pairs > 0 else (1 if args.workload == "4k" else 48))
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if collective:
+        with stdout_to_stderr():
+            if world > 1:
+                dist.barrier()
+            dist.destroy_process_group()
     return 0
 
 

@@ -42,8 +42,10 @@ int main(int argc, char** argv)
             read_frame(VO.imgLT2, VO.imgRT2);
             vo::Image<float> disparityMapT1 = VO.computeDisparity(VO.imgLT1, VO.imgRT1);
             vo::Image<double> depthMapT1 = VO.computeDepthMap(disparityMapT1);
-            if (i == 0 && argc > 4) VO.writeToPLY(argv[4]); /* the reference writes the cloud of a frame from here when asked to */
             std::vector<vo_point2f> featurePointsT1 = VO.getFeaturesFAST(VO.imgLT1);
+            /* the reference writes the cloud of a frame from computeDepthMap when asked to; the writer works on its arguments,
+             * so any point of the loop will do (here: after FAST, when the device holds no depth map of its own any more) */
+            if (i == 0 && argc > 4) VO.writeToPLY(depthMapT1, VO.imgLT1, 3000, -1, argv[4]);
             std::vector<vo_point2f> featurePointsT2 = VO.matchFeatureKLT(featurePointsT1);
             auto t = VO.estimateMotion(featurePointsT1, featurePointsT2, depthMapT1);
             estimatedTrajectory.push_back(t);

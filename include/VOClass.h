@@ -55,6 +55,7 @@ struct Image {
 
 class VOClass {
     int frameW, frameH;
+    int depthThreshold = 3000;
     vo_ctx* ctx = nullptr;
     std::array<double, 12> projectionCL{}, projectionCR{};
     std::vector<std::array<double, 3>> groundTruth;
@@ -86,6 +87,7 @@ public:
     {
         vo_params p;
         if (params) p = *params; else vo_default_params(&p, width, height);
+        depthThreshold = p.depth_thresh;
         int rc = vo_create(&p, device, &ctx);
         if (rc != VO_OK) throw vo::Error(rc, vo_create_error());
     }
@@ -123,12 +125,18 @@ public:
         return depth;
     }
 
-    /* point cloud of the current depth map as the reference writes it (VOClass::writeToPLY, Source/VOClassUtils.cpp:111-157,
-     * called from computeDepthMap, Source/VOClass.cpp:330-360): "row col -z g g g" for every pixel whose depth is not
-     * above depthThresh.  The vertices are compacted on the GPU; numVertices is the header's count as the caller computed
-     * it (the reference derives it from a histogram), by default the number of vertices written.  Call after computeDepthMap. */
-    int writeToPLY(const std::string& plyFilePath, int numVertices = -1)
+    /* point cloud of a depth map as the reference writes it (VOClass::writeToPLY(depthMap, colors, depthThresh, numVertices),
+     * Source/VOClassUtils.cpp:111-157, called from computeDepthMap, Source/VOClass.cpp:330-360): "row col -z g g g" for every
+     * pixel whose depth is not above depthThresh, colours from the image handed over.  Works on its arguments like the
+     * reference, so it can be called at any point of the loop; the vertices are compacted on the GPU in the writer's order.
+     * numVertices is the header's count as the caller computed it (the reference derives it from a histogram), negative: the
+     * number of vertices written.  depthThresh must be the context's depth_thresh (3000 in the reference's only call). */
+    int writeToPLY(vo::Image<double> depthMap, vo::Image<uint8_t> colors, int depthThresh, int numVertices, const std::string& plyFilePath)
     {
+        if (depthMap.rows != frameH || depthMap.cols != frameW) throw vo::Error(VO_ERR_BAD_ARG, "depth map size differs from frameW x frameH");
+        if (depthThresh != depthThreshold) throw vo::Error(VO_ERR_BAD_ARG, "depthThresh differs from the context's depth_thresh");
+        syncImages(&colors, nullptr);
+        check(vo_set_depth(ctx, 0, depthMap.ptr()));
         int n = 0;
         check(vo_get_depth_cloud(ctx, 0, nullptr, 0, &n));
         std::vector<vo_cloud_point> pts((size_t)n);

@@ -78,7 +78,7 @@ typedef struct {
     int ransac_iters;         /* 100 */
     float ransac_reproj;      /* 8.0 */
     double ransac_conf;       /* 0.99 */
-    int ransac_chunk;         /* hypotheses solved on the host and scored on the GPU per round (8) */
+    int ransac_chunk;         /* hypotheses solved on the host and scored on the GPU per round (8; at most 1024) */
     int host_threads;         /* host worker threads for the minimal solvers of a batch (0 = auto) */
 } vo_params;
 

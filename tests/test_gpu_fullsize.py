@@ -80,3 +80,42 @@ def test_kitti200_every_frame_against_the_oracle_fixture():
     assert abs(rmse - float(fx["rmse_vs_truth"])) <= 1e-3 * path
     print("kitti200: %d steps bit-exact (disparity, FAST); worst pose difference %.1e rad / %.1e m, worst track %.1e px, "
           "trajectory within %.1e m of the oracle's, RMSE against the generating poses %.3f m" % (ns, worst_rot, worst_t, worst_px, ate, rmse))
+
+
+def test_frame4k_256_disparities_against_the_oracle_fixture():
+    """the 4K configuration at full size (3840x2160, 256 disparity levels: stripes of 540 rows with 60 warm-up rows, 16
+    disparities per lane): disparity before and after the median and the FAST list bit-exact against the oracle's hashes
+    (tests/golden/frame4k_d256.npz, made by tests/golden/make_frame4k.py), and the whole main-loop step on that frame pair"""
+    fx = np.load(os.path.join(GOLDEN, "frame4k_d256.npz"))
+    W, H, D, seed = (int(fx[k]) for k in ("width", "height", "num_disparities", "seed"))
+    scene = synth.pixel_matched_scene(W)
+    frames = render_frames(seed, W, H, 2, **scene)
+    got_hash = np.array([[h64(f[0]), h64(f[1])] for f in frames], dtype=np.uint64)
+    assert np.array_equal(got_hash, fx["frame_hash"]), "the rendered input frames differ from those the fixture was made from"
+    seq = synth.Sequence(seed=seed, width=W, height=H, **scene)
+    ctx = abi.Context(abi.default_params(W, H, max_batch=1, num_disparities=D, max_features=98304))
+    ctx.set_calib(seq.P0, seq.P1)
+    ctx.set_images(frames[0][0], frames[0][1], frames[1][0], frames[1][1])
+    Rt, info = ctx.step()
+    d16 = ctx.disparity16(0)
+    pre = ctx.tap(abi.TAP_DISP_PREMEDIAN, 0)
+    s = fx["samples"]
+    wrong = [(int(y), int(x), int(d16[y, x]), int(w)) for y, x, w, _ in s if d16[y, x] != w]
+    assert not wrong, "sampled disparities differ from the oracle's (y, x, got, want): %s" % wrong[:8]
+    wrong = [(int(y), int(x), int(pre[y, x]), int(w)) for y, x, _, w in s if pre[y, x] != w]
+    assert not wrong, "sampled pre-median disparities differ from the oracle's: %s" % wrong[:8]
+    assert h64(pre) == int(fx["premedian_hash"])
+    assert h64(d16) == int(fx["disp_hash"])
+    assert int((d16[:, D:] < 0).sum()) == int(fx["n_invalid"])
+    assert h64(ctx.features(0)) == int(fx["fast_hash"])
+    f = info[0]
+    assert (f.n_features, f.n_matched, f.n_object_points) == (int(fx["n_fast"]), int(fx["n_matched"]), int(fx["n_obj"]))
+    assert (f.ok, f.iters_run, f.best_inliers) == (int(fx["pnp_ok"]), int(fx["pnp_iters"]), int(fx["pnp_inliers"]))
+    t1, t2 = ctx.matches(0)
+    if h64(np.concatenate([t1, t2])) != int(fx["match_hash"]):   # not bit-identical: the 0.01 px tolerance on the kept sample
+        k = fx["match_sample"].shape[1]
+        assert np.abs(t1[:k] - fx["match_sample"][0]).max() <= 0.01 and np.abs(t2[:k] - fx["match_sample"][1]).max() <= 0.01
+    want = fx["Rt"]
+    assert rotation_angle(want[:3, :3], Rt[0][:3, :3]) <= 1e-4 and np.abs(Rt[0][:3, 3] - want[:3, 3]).max() <= 1e-3
+    assert f.n_matched >= 0.7 * f.n_features       # the scene keeps the matching circle as closed as at KITTI shape
+    ctx.close()

@@ -28,12 +28,16 @@ def test_main_loop_with_the_python_mirror(tmp_path):
         # the reference patches its argument in place (0 and -1 become 0.1f)
         bad = (before == 0.0) | (before == -1.0)
         assert bad.any() and np.all(disparityMapT1[bad] == np.float32(0.1)) and np.array_equal(disparityMapT1[~bad], before[~bad])
+        featurePointsT1 = VO.getFeaturesFAST(VO.imgLT1)
         if i == 0:
-            n = VO.writeToPLY(str(tmp_path / "gpu.ply"))
+            # the writer works on its arguments, so it can be called at any point of the loop (here: after FAST, when the
+            # device no longer holds a depth map of its own)
+            n = VO.writeToPLY(depthMapT1, VO.imgLT1, 3000, plyFilePath=str(tmp_path / "gpu.ply"))
             written, _ = kitti.write_depth_ply(str(tmp_path / "host.ply"), depthMapT1, VO.imgLT1)
             assert n == written
             assert (tmp_path / "gpu.ply").read_text().splitlines()[10:] == (tmp_path / "host.ply").read_text().splitlines()[10:]
-        featurePointsT1 = VO.getFeaturesFAST(VO.imgLT1)
+            with pytest.raises(TypeError):
+                VO.estimateMotion(featurePointsT1, featurePointsT1)   # the depth map is a required argument, as in the reference
         n_fast = len(featurePointsT1)
         featurePointsT1, featurePointsT2 = VO.matchFeatureKLT(featurePointsT1)
         assert 0 < len(featurePointsT1) == len(featurePointsT2) <= n_fast

@@ -3,6 +3,8 @@
 #include "small_linalg.h"
 #include <math.h>
 #include <string.h>
+#include <array>
+#include <vector>
 #include <thread>
 #include <atomic>
 #include <functional>
@@ -850,7 +852,7 @@ struct FrameRansac {
     double best_r[3] = {0, 0, 0}, best_t[3] = {0, 0, 0};
     std::vector<uint8_t> best_mask;
     int nh = 0;                // hypotheses in the current round
-    double hr[64][3], ht[64][3];
+    std::vector<std::array<double, 3>> hr, ht; // the round's rvec / tvec, `ransac_chunk` of them
     int best_h = -1;           // hypothesis of this round that became the best model
 };
 
@@ -892,6 +894,7 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
         FrameRansac& f = fr[b];
         f.k = k; f.obj = objs[b].data(); f.img = imgs[b].data();
         f.niters = std::max(c->p.ransac_iters, 1);
+        f.hr.resize(chunk); f.ht.resize(chunk);
         if (k < 4) { f.failed = true; status = VO_ERR_NOT_ENOUGH_POINTS; } // the original asserts at least 4 points
         else if (k == 4 || k == model_points) f.direct = true;          // no sampling: one minimal solve on all points
         else f.active = true;
@@ -919,9 +922,9 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
                 draw_subset(f.rng, f.k, model_points, idx);
                 vo_point3f so[5]; vo_point2f si[5];
                 for (int j = 0; j < 5; j++) { so[j] = f.obj[idx[j]]; si[j] = f.img[idx[j]]; }
-                epnp(so, si, 5, K, f.hr[h], f.ht[h]);
+                epnp(so, si, 5, K, f.hr[h].data(), f.ht[h].data());
                 double R[9];
-                rodrigues_to_matrix(f.hr[h], R, nullptr);
+                rodrigues_to_matrix(f.hr[h].data(), R, nullptr);
                 double* dst = h_hyp + ((size_t)b * chunk + h) * 12;
                 memcpy(dst, R, sizeof(R)); dst[9] = f.ht[h][0]; dst[10] = f.ht[h][1]; dst[11] = f.ht[h][2];
             }
@@ -943,7 +946,7 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
                 const int good = h_cnt[(size_t)b * chunk + h];
                 if (good > std::max(f.max_good, model_points - 1)) {
                     f.max_good = good; f.best_h = h;
-                    memcpy(f.best_r, f.hr[h], sizeof(f.best_r)); memcpy(f.best_t, f.ht[h], sizeof(f.best_t));
+                    memcpy(f.best_r, f.hr[h].data(), sizeof(f.best_r)); memcpy(f.best_t, f.ht[h].data(), sizeof(f.best_t));
                     f.niters = update_num_iters(c->p.ransac_conf, (double)(f.k - good) / f.k, model_points, f.niters);
                 }
                 f.iter++;

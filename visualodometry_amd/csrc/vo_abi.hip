@@ -129,7 +129,7 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     memset(c->ev0, 0, sizeof(c->ev0)); memset(c->ev1, 0, sizeof(c->ev1)); memset(c->ev_used, 0, sizeof(c->ev_used));
     memset(c->stage_ms, 0, sizeof(c->stage_ms)); memset(c->stage_calls, 0, sizeof(c->stage_calls));
     if (c->p.ransac_chunk < 1) c->p.ransac_chunk = 8;
-    if (c->p.ransac_chunk > 64) c->p.ransac_chunk = 64;
+    if (c->p.ransac_chunk > 1024) c->p.ransac_chunk = 1024;
     c->p.fast_threshold = std::min(std::max(c->p.fast_threshold, 0), 255);
     int rc = derive(c);
     if (rc != VO_OK) { delete c; return rc; }

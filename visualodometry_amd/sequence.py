@@ -101,7 +101,7 @@ def gather_trajectories(local, n_sequences, max_steps, group=None):
         a = np.asarray(Rt, dtype=np.float64).reshape(-1, 16)
         buf[i, first:first + a.shape[0]] = torch.from_numpy(a)
         cnt[i] = a.shape[0]
-    if world > 1:
+    if dist.is_initialized():   # a one-rank group runs the same collective on the same device tensors
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
         buf, cnt = buf.to(dev), cnt.to(dev)
         bufs = [torch.empty_like(buf) for _ in range(world)]
@@ -129,7 +129,7 @@ def gather_point_clouds(clouds, cap, group=None):
             raise ValueError("point set %d has %d points, capacity %d" % (i, a.shape[0], cap))
         buf[i, :a.shape[0]] = torch.from_numpy(a)
         cnt[i] = a.shape[0]
-    if world == 1:
+    if not dist.is_initialized():
         return [[buf[i, :int(cnt[i])].numpy().copy() for i in range(n)]]
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     buf, cnt = buf.to(dev), cnt.to(dev)

@@ -17,17 +17,28 @@ KITTI_P1_03 = -386.1448
 KITTI_SEQ_LENGTHS = (4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201)
 
 
-def calib(width=KITTI_W, height=KITTI_H):
-    """P0, P1 (3x4 f64).  Other sizes scale the KITTI intrinsics by width/1241 and keep the 0.537 m baseline."""
+def calib(width=KITTI_W, height=KITTI_H, baseline_scale=1.0):
+    """P0, P1 (3x4 f64).  Other sizes scale the KITTI intrinsics by width/1241 and keep the 0.537 m baseline
+    (times baseline_scale)."""
     s = width / float(KITTI_W)
     fx = KITTI_FX * s
     cx = KITTI_CX * s
     cy = KITTI_CY * (height / float(KITTI_H))
-    b = -KITTI_P1_03 / KITTI_FX
+    b = -KITTI_P1_03 / KITTI_FX * baseline_scale
     P0 = np.array([[fx, 0, cx, 0], [0, fx, cy, 0], [0, 0, 1, 0]], dtype=np.float64)
     P1 = P0.copy()
     P1[0, 3] = -fx * b
     return P0, P1
+
+
+def pixel_matched_scene(width):
+    """Sequence(...) keyword arguments that give an image `width` pixels wide the per-pixel statistics of the 1241-pixel
+    one: texture wavelengths, stereo baseline, forward step and yaw rate all scaled by 1241 / width, so that corner density
+    per pixel, disparities and frame-to-frame flow (in pixels) are those of the KITTI-shape sequence.  Without it a wider
+    image of the same scene shows the same surfaces magnified: fewer corners per pixel and flows beyond the reach of a
+    4-level pyramid (at 3840 pixels only a third of the features close the matching circle)."""
+    s = KITTI_W / float(width)
+    return dict(step=0.8 * s, yaw_rate=0.02 * s, texture_scale=s, baseline_scale=s)
 
 
 def _hash2(seed, plane, octave, ix, iy):
@@ -83,10 +94,14 @@ class Sequence:
     """One synthetic stereo sequence.  pose(i) is the 3x4 camera-to-world [R|t] of the left camera."""
 
     def __init__(self, seed=1000, width=KITTI_W, height=KITTI_H, step=0.8, yaw_rate=0.02, yaw_period=50.0,
-                 wall=7.0, ground=1.65, far=6000.0, contrast=130.0):
+                 wall=7.0, ground=1.65, far=6000.0, contrast=130.0, texture_scale=1.0, baseline_scale=1.0):
+        """texture_scale: every texture wavelength (in metres on the surfaces) is multiplied by it; baseline_scale: the
+        stereo baseline is.  With both, `step` and `yaw_rate` set to 1241 / width, an image of `width` pixels has the texture
+        statistics, disparities and frame-to-frame flow, all counted in pixels, of the 1241-pixel one."""
         self.seed = int(seed)
         self.width, self.height = int(width), int(height)
-        self.P0, self.P1 = calib(width, height)
+        self.texture_scale = float(texture_scale)
+        self.P0, self.P1 = calib(width, height, baseline_scale)
         self.fx, self.fy = self.P0[0, 0], self.P0[1, 1]
         self.cx, self.cy = self.P0[0, 2], self.P0[1, 2]
         self.baseline = self.P1[0, 3] / (-self.fx)
@@ -144,7 +159,7 @@ class Sequence:
             m = plane == pid
             if not m.any():
                 continue
-            scale = 1.0 if pid < 3 else 40.0  # the backdrop is far away: use a coarser texture there
+            scale = (1.0 if pid < 3 else 40.0) * self.texture_scale  # the backdrop is far away: use a coarser texture there
             img[m] = _texture(self.seed, pid, a[m] / scale, b[m] / scale, footprint[m] / scale)
         out = np.rint(img * self.contrast + 128.0)
         return np.clip(out, 0, 255).astype(np.uint8)

@@ -55,10 +55,17 @@ class VOClass:
         disparityMap[(disparityMap == 0.0) | (disparityMap == -1.0)] = np.float32(0.1)
         return self.ctx.depth(0)
 
-    def writeToPLY(self, plyFilePath, numVertices=None):
-        """VOClass::writeToPLY (Source/VOClassUtils.cpp:111-157) for the current depth map: the vertices are compacted on
-        the GPU in the writer's order; numVertices is the header's count (default: the vertices written)."""
+    def writeToPLY(self, depthMap, colors, depthThresh=None, numVertices=None, plyFilePath="depth.ply"):
+        """VOClass::writeToPLY(depthMap, colors, depthThresh, numVertices) (Source/VOClassUtils.cpp:111-157): "row col -z g g g"
+        for every pixel of depthMap that is not above depthThresh, colours from the image handed over.  Works on its
+        arguments like the reference (callable at any point of the loop); the vertices are compacted on the GPU in the
+        writer's order.  numVertices is the header's count (default: the vertices written); depthThresh must be the
+        context's depth_thresh (3000 in the reference's only call, Source/VOClass.cpp:358)."""
         from . import kitti
+        if depthThresh is not None and int(depthThresh) != int(self.params.depth_thresh):
+            raise ValueError("depthThresh %s differs from the context's depth_thresh %d" % (depthThresh, self.params.depth_thresh))
+        self._sync_images(colors, None)
+        self.ctx.set_depth(depthMap, 0)
         return kitti.write_cloud_ply(plyFilePath, self.ctx.depth_cloud(0), numVertices)
 
     def getFeaturesFAST(self, img):
@@ -73,11 +80,12 @@ class VOClass:
         self.ctx.match_klt()
         return self.ctx.matches(0)
 
-    def estimateMotion(self, featurePointsT1, featurePointsT2, depthMap=None):
+    def estimateMotion(self, featurePointsT1, featurePointsT2, depthMap):
+        """depthMap is required, as in the reference (Include/VOClass.h:98-100): depths are looked up in the map handed over
+        (Source/VOClass.cpp:418), whatever the device computed last."""
         assert len(featurePointsT1) == len(featurePointsT2)
         self.ctx.set_matches(featurePointsT1, featurePointsT2, 0)
-        if depthMap is not None:   # the reference looks depths up in the map it is handed (Source/VOClass.cpp:418)
-            self.ctx.set_depth(depthMap, 0)
+        self.ctx.set_depth(depthMap, 0)
         self.ctx.triangulate()
         Rt, info = self.ctx.estimate_motion()
         self.lastInfo = info[0]
