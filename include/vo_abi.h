@@ -80,6 +80,12 @@ typedef struct {
     double ransac_conf;       /* 0.99 */
     int ransac_chunk;         /* hypotheses solved on the host and scored on the GPU per round (8; at most 1024) */
     int host_threads;         /* host worker threads for the minimal solvers of a batch (0 = auto) */
+    /* Accumulators of the tracker's structure tensor and mismatch vector.  0: exact integer sums (order free), the only mode
+     * this library computes.  OpenCV sums them in float (its integer accumulators belong to 32-bit ARM builds without NEON),
+     * partly in 4-lane vector partial sums whose order depends on the instruction set; the CPU oracle restates those orders
+     * as modes 1, 4 (NEON) and 8 (x86) of the same field, where 99.9 % of the tracks stay within 0.01 px of mode 0 and no
+     * relative pose moves by more than 5e-7 rad / 2e-5 m.  Any other value here: VO_ERR_UNSUPPORTED from vo_create. */
+    int lk_accum;             /* 0 */
 } vo_params;
 
 typedef struct {
@@ -163,7 +169,9 @@ int vo_set_features(vo_ctx* ctx, int b, const vo_point2f* pts, int n);
  * lives in a fixed device array of the library instead of a context, so the image is limited to 2^21 pixels and 4096
  * rows (VO_ERR_CAPACITY beyond; the text is in vo_create_error()).  img_dev, out_dev (cap points) and n_out_dev (one int:
  * min(number of corners, cap)) are device pointers on the CURRENT device; the work is enqueued on `stream` (a hipStream_t,
- * may be NULL) and not waited for.  All calls on one GPU share that GPU's scratch: calls that overlap on one GPU race. */
+ * may be NULL) and not waited for.  All calls on one GPU share that GPU's scratch: calls that overlap on one GPU race.
+ * The address of a GPU's scratch is looked up once (a code-object load and a lock, neither allowed under stream capture):
+ * by vo_create for its device, or by the first call here on a device; a caller that captures makes one of the two first. */
 int vo_detect_fast_noalloc(const uint8_t* img_dev, int width, int height, size_t stride, int threshold, int nms,
                            vo_point2f* out_dev, int cap, int* n_out_dev, void* stream);
 
@@ -233,7 +241,9 @@ int vo_pyramid_info(vo_ctx* ctx, int level, int* w, int* h, int* max_level);
 typedef enum {
     VO_ST_PREFILTER = 0, /* 1: not in use */ VO_ST_VPATH = 2, VO_ST_HPATH_FWD = 3, VO_ST_HPATH_BWD = 4, VO_ST_LRCHECK = 5 /* consistency check + median */,
     /* 6: not in use */ VO_ST_FAST = 7, VO_ST_PYRAMID = 8, VO_ST_LK = 9, VO_ST_FILTER = 10, VO_ST_TRIANGULATE = 11,
-    VO_ST_PNP_SCORE = 12, VO_ST_PNP_HOST = 13, VO_ST_STEP_WALL = 14
+    VO_ST_PNP_SCORE = 12, VO_ST_PNP_HOST = 13, VO_ST_STEP_WALL = 14,
+    VO_ST_PNP_SERIAL = 15 /* host solver sections that found the process's worker pool busy with another thread's section and ran
+                           * on the calling thread alone (one pool per process, shared by its contexts) */
 } vo_stage;
 int vo_set_timing(vo_ctx* ctx, int enable);
 int vo_get_timing(vo_ctx* ctx, double* ms, long long* calls, int reset);

@@ -31,6 +31,7 @@ class Params(C.Structure):
         ("lk_epsilon", C.c_double), ("lk_min_eig", C.c_double),
         ("loop_threshold", C.c_int), ("depth_thresh", C.c_int),
         ("ransac_iters", C.c_int), ("ransac_reproj", C.c_float), ("ransac_conf", C.c_double),
+        ("lk_accum", C.c_int),
     ]
 
 

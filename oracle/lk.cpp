@@ -1,9 +1,27 @@
 /* CPU ORACLE (test infrastructure only) — pyramidal Lucas–Kanade + circular matching.
  * Restates cv::calcOpticalFlowPyrLK as called at reference Source/VOClassFeatures.cpp:104-111
  * (OpenCV 4.5.4 video/src/lkpyramid.cpp: buildOpticalFlowPyramid, calcSharrDeriv,
- * LKTrackerInvoker with the integer (int64) accumulator variant; imgproc pyrDown) and the
+ * LKTrackerInvoker; imgproc pyrDown) and the
  * reference's own filtering at Source/VOClassFeatures.cpp:134-201, Source/VOClassUtils.cpp:61-91.
  * Parity unpinned (see vo_oracle.h).
+ *
+ * Accumulators of the tracker (orc_params.lk_accum).  lkpyramid.cpp declares them as
+ *     #if defined __arm__ && !CV_NEON   typedef int64 acctype; typedef int itemtype;
+ *     #else                             typedef float acctype; typedef float itemtype;
+ * so every mainstream build (x86, and arm64 with NEON, which the reference's author used) sums the structure tensor and the
+ * mismatch vector in FLOAT, part of it in 4-lane vector partial sums whose order depends on the instruction set.  Integer
+ * sums are what a 32-bit ARM build without NEON computes.  Modes:
+ *     0  exact integer sums (order free; what the GPU library computes)
+ *     1  float, plain scan order (no vector partial sums)
+ *     4  float in the order of the NEON block of lkpyramid.cpp (restated from knowledge of that file, medium confidence):
+ *        tensor: 4 lanes step x by 4 (x <= win - 4) over all window rows, each lane adding the float of its exact integer
+ *        product; the rest of every row goes to the scalar accumulator; at the end acc += ((n0 + n1) + n2) + n3.
+ *        mismatch: 4 lanes step x by 8 (x <= win - 8), lane j adds the float of the INTEGER sum of its two products (pixels
+ *        x + j and x + j + 4); rest of the row scalar; at the end acc += (float)(((n0 + n1) + n2) + n3).
+ *     8  float in the order of the 128-bit universal-intrinsic block (x86 SSE2; low confidence on the lane permutation):
+ *        tensor: 4 lanes step x by 8, lane j adds pixel x + j then pixel x + 4 + j; rest scalar; acc += (q0 + q2) + (q1 + q3).
+ *        mismatch: two 4-lane vectors step x by 8; the lanes that feed b1 hold float(int(p[x] + p[x+4])), (p[x+1] + p[x+5]) in one
+ *        vector and (p[x+2] + p[x+6]), (p[x+3] + p[x+7]) in the other; acc += (v0.a + v1.a) + (v0.b + v1.b).
  */
 #include "vo_oracle.h"
 #include <vector>
@@ -140,10 +158,68 @@ static long long g_lk_levels = 0, g_lk_iters = 0, g_lk_hist[52];
 static int* g_lk_log = nullptr;
 static long long g_lk_log_pos = 0, g_lk_log_cap = 0;
 
+/* Sum of the win x win integer products `p` (row-major) as the tracker's accumulators form it: see the modes at the top
+ * of this file.  mismatch = false: a term of the structure tensor; true: a term of the mismatch vector (the two differ in
+ * how the vector blocks walk a row).  Returned as float (acctype) before the 2^-20 scaling. */
+float window_sum(const int* p, int win, int accum, bool mismatch)
+{
+    if (accum == 0) {
+        int64_t s = 0;
+        for (int i = 0; i < win * win; i++) s += p[i];
+        return (float)s; /* acctype int64 -> float in `iA11 * FLT_SCALE` */
+    }
+    if (accum == 1) {
+        float s = 0;
+        for (int i = 0; i < win * win; i++) s += (float)p[i];
+        return s;
+    }
+    float acc = 0.f;
+    if (accum == 4) {
+        float n[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int y = 0; y < win; y++) {
+            const int* r = p + (size_t)y * win;
+            int x = 0;
+            if (!mismatch) for (; x <= win - 4; x += 4) for (int j = 0; j < 4; j++) n[j] += (float)r[x + j];
+            else for (; x <= win - 8; x += 8) for (int j = 0; j < 4; j++) n[j] += (float)(r[x + j] + r[x + j + 4]);
+            for (; x < win; x++) acc += (float)r[x];
+        }
+        const float lanes = ((n[0] + n[1]) + n[2]) + n[3];
+        acc += lanes;
+        return acc;
+    }
+    /* accum == 8 */
+    if (!mismatch) {
+        float q[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int y = 0; y < win; y++) {
+            const int* r = p + (size_t)y * win;
+            int x = 0;
+            for (; x <= win - 8; x += 8) {
+                for (int j = 0; j < 4; j++) q[j] += (float)r[x + j];
+                for (int j = 0; j < 4; j++) q[j] += (float)r[x + 4 + j];
+            }
+            for (; x < win; x++) acc += (float)r[x];
+        }
+        acc += (q[0] + q[2]) + (q[1] + q[3]);
+        return acc;
+    }
+    float v0a = 0.f, v0b = 0.f, v1a = 0.f, v1b = 0.f;
+    for (int y = 0; y < win; y++) {
+        const int* r = p + (size_t)y * win;
+        int x = 0;
+        for (; x <= win - 8; x += 8) {
+            v0a += (float)(r[x] + r[x + 4]); v0b += (float)(r[x + 1] + r[x + 5]);
+            v1a += (float)(r[x + 2] + r[x + 6]); v1b += (float)(r[x + 3] + r[x + 7]);
+        }
+        for (; x < win; x++) acc += (float)r[x];
+    }
+    acc += (v0a + v1a) + (v0b + v1b);
+    return acc;
+}
+
 /* LKTrackerInvoker for one point on one level. */
 void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, orc_point2f* next_pt_io,
                  uint8_t* status, float* err, int level, int max_level, int win, int max_count, double eps2,
-                 float min_eig_thr)
+                 float min_eig_thr, int accum)
 {
     const float half = (win - 1) * 0.5f;
     orc_point2f prevPt = {prev_pt0.x * (float)(1. / (1 << level)), prev_pt0.y * (float)(1. / (1 << level))};
@@ -167,9 +243,6 @@ void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, or
     int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
 
     std::vector<int16_t> Iw((size_t)win * win), dIw((size_t)win * win * 2);
-    int64_t iA11 = 0, iA12 = 0, iA22 = 0;
-    const bool facc = (orc_get_variant() & ORC_VAR_LK_FLOAT_ACC) != 0;
-    float fA11 = 0, fA12 = 0, fA22 = 0;
     const int stepI = I.stride, dstep = I.stride * 2;
     for (int y = 0; y < win; y++) {
         const uint8_t* src = I.at(y + ipy, ipx);
@@ -181,14 +254,18 @@ void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, or
             Iw[(size_t)y * win + x] = (int16_t)ival;
             dIw[((size_t)y * win + x) * 2] = (int16_t)ixval;
             dIw[((size_t)y * win + x) * 2 + 1] = (int16_t)iyval;
-            iA11 += (int)(ixval * ixval);
-            iA12 += (int)(ixval * iyval);
-            iA22 += (int)(iyval * iyval);
-            fA11 += (float)(ixval * ixval); fA12 += (float)(ixval * iyval); fA22 += (float)(iyval * iyval);
         }
     }
-    float A11 = iA11 * FLT_SCALE, A12 = iA12 * FLT_SCALE, A22 = iA22 * FLT_SCALE;
-    if (facc) { A11 = fA11 * FLT_SCALE; A12 = fA12 * FLT_SCALE; A22 = fA22 * FLT_SCALE; }
+    std::vector<int> prod((size_t)win * win);
+    float Asum[3];
+    for (int q = 0; q < 3; q++) {
+        for (int i = 0; i < win * win; i++) {
+            const int ix = dIw[(size_t)i * 2], iy = dIw[(size_t)i * 2 + 1];
+            prod[i] = q == 0 ? ix * ix : q == 1 ? ix * iy : iy * iy;
+        }
+        Asum[q] = window_sum(prod.data(), win, accum, false);
+    }
+    float A11 = Asum[0] * FLT_SCALE, A12 = Asum[1] * FLT_SCALE, A22 = Asum[2] * FLT_SCALE;
     float Dt = A11 * A22 - A12 * A12;
     float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * win * win);
     if (minEig < min_eig_thr || Dt < FLT_EPSILON) {
@@ -196,6 +273,7 @@ void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, or
         return;
     }
     Dt = 1.f / Dt;
+    std::vector<int> prod2((size_t)win * win);
 
     nextPt.x -= half; nextPt.y -= half;
     orc_point2f prevDelta = {0, 0};
@@ -214,20 +292,16 @@ void track_point(const Level& I, const Level& J, const orc_point2f& prev_pt0, or
         iw01 = cv_round(a * (1.f - b) * (1 << W_BITS));
         iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
         iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-        int64_t ib1 = 0, ib2 = 0;
-        float fb1 = 0, fb2 = 0;
         for (int y = 0; y < win; y++) {
             const uint8_t* Jp = J.at(y + iny, inx);
             for (int x = 0; x < win; x++) {
                 int diff = descale(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stepJ] * iw10 + Jp[x + stepJ + 1] * iw11, W_BITS - 5) -
                            Iw[(size_t)y * win + x];
-                ib1 += (int)(diff * dIw[((size_t)y * win + x) * 2]);
-                ib2 += (int)(diff * dIw[((size_t)y * win + x) * 2 + 1]);
-                fb1 += (float)(diff * dIw[((size_t)y * win + x) * 2]); fb2 += (float)(diff * dIw[((size_t)y * win + x) * 2 + 1]);
+                prod[(size_t)y * win + x] = diff * dIw[((size_t)y * win + x) * 2];
+                prod2[(size_t)y * win + x] = diff * dIw[((size_t)y * win + x) * 2 + 1];
             }
         }
-        float b1 = ib1 * FLT_SCALE, b2 = ib2 * FLT_SCALE;
-        if (facc) { b1 = fb1 * FLT_SCALE; b2 = fb2 * FLT_SCALE; }
+        float b1 = window_sum(prod.data(), win, accum, true) * FLT_SCALE, b2 = window_sum(prod2.data(), win, accum, true) * FLT_SCALE;
         orc_point2f delta = {(float)((A12 * b2 - A22 * b1) * Dt), (float)((A12 * b1 - A11 * b2) * Dt)};
         nextPt.x += delta.x; nextPt.y += delta.y;
         next_pt_io->x = nextPt.x + half; next_pt_io->y = nextPt.y + half;
@@ -274,13 +348,15 @@ void lk_with_pyramids(const Pyr& P, const Pyr& N, const orc_point2f* prev_pts, i
     double eps2 = eps * eps;
     int levels = std::min(P.levels, N.levels);
     for (int i = 0; i < n; i++) { status[i] = 1; if (err) err[i] = 0; }
+    /* the sensitivity switch of older fixtures (float sums in scan order) maps onto mode 1 */
+    const int accum = (p->lk_accum == 0 && (orc_get_variant() & ORC_VAR_LK_FLOAT_ACC)) ? 1 : p->lk_accum;
 
     for (int level = levels; level >= 0; level--) {
 #pragma omp parallel for num_threads(orc_get_threads()) schedule(static)
         for (int i = 0; i < n; i++) {
             const long long before = g_lk_iters;
             track_point(P.lv[level], N.lv[level], prev_pts[i], &next_pts[i], &status[i], err ? &err[i] : nullptr,
-                        level, levels, p->lk_win, max_count, eps2, (float)p->lk_min_eig);
+                        level, levels, p->lk_win, max_count, eps2, (float)p->lk_min_eig, accum);
             if (g_lk_log && g_lk_log_pos < g_lk_log_cap) g_lk_log[g_lk_log_pos++] = (int)(g_lk_iters - before); /* single-threaded runs only */
         }
     }

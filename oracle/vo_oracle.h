@@ -60,6 +60,9 @@ typedef struct {
     int ransac_iters;       /* 100 */
     float ransac_reproj;    /* 8.0 */
     double ransac_conf;     /* 0.99 */
+    /* accumulators of the LK tracker (oracle/lk.cpp): 0 exact integer sums, 1 float in scan order, 4 float in the order of
+     * OpenCV's NEON block (arm64, the reference author's machine), 8 float in the order of its 128-bit x86 block */
+    int lk_accum;           /* 0 */
 } orc_params;
 
 void orc_default_params(orc_params* p, int width, int height);
@@ -127,7 +130,7 @@ enum {
     ORC_VAR_PATH_START_C = 1,      /* first pixel of a path: L = C (instead of C - P2, zero state with zero minimum) */
     ORC_VAR_DISP12_ZERO = 2,       /* disp12MaxDiff <= 0 stays 0 (instead of being taken as 1) */
     ORC_VAR_RAW_BORDER_PIXEL = 4,  /* raw-intensity channel keeps the pixel in columns 0 and W-1 (instead of the table's zero entry) */
-    ORC_VAR_LK_FLOAT_ACC = 8,      /* LK sums in float, in scan order (instead of exact integer sums) */
+    ORC_VAR_LK_FLOAT_ACC = 8,      /* LK sums in float, in scan order (instead of exact integer sums): same as lk_accum = 1 */
     ORC_VAR_LK_NO_ERR_STATUS = 16  /* LK: no re-test of the final window position after the iterations */
 };
 void orc_set_variant(unsigned flags);

@@ -33,8 +33,13 @@ ASSUMPTIONS = {
     "disp12_max_diff_zero": (ob.VAR_DISP12_ZERO, {}, "disp12MaxDiff = 0 is taken as 1 by the 3-way code", "0 stays 0"),
     "raw_channel_border": (ob.VAR_RAW_BORDER_PIXEL, {}, "the raw-intensity channel of the pixel cost holds the table's zero entry (15) in columns 0 and W-1",
                            "it holds the pixel"),
-    "lk_float_accumulators": (ob.VAR_LK_FLOAT_ACC, {}, "LK structure tensor and mismatch vector are exact integer sums (the NEON build of the reference's author)",
-                              "float sums in scan order (a build without that path)"),
+    "lk_float_accumulators": (ob.VAR_LK_FLOAT_ACC, {}, "LK structure tensor and mismatch vector are exact integer sums (lk_accum = 0; what the GPU library computes)",
+                              "float sums in plain scan order (lk_accum = 1)"),
+    "lk_float_accumulators_neon_order": (0, {"lk_accum": 4}, "exact integer sums (lk_accum = 0)",
+                                         "float sums in the order of OpenCV's NEON block (lk_accum = 4: arm64, the build of the reference's author; "
+                                         "acctype is float in every build but 32-bit ARM without NEON)"),
+    "lk_float_accumulators_sse_order": (0, {"lk_accum": 8}, "exact integer sums (lk_accum = 0)",
+                                        "float sums in the order of OpenCV's 128-bit x86 block (lk_accum = 8)"),
     "lk_error_pass_status": (ob.VAR_LK_NO_ERR_STATUS, {}, "after the iterations the final window position is tested again and can clear the status",
                              "no such test"),
 }
@@ -67,12 +72,16 @@ def compare(base, var):
     changed = base["d16"] != var["d16"]
     both = (base["lst"].min(axis=0) == 1) & (var["lst"].min(axis=0) == 1)
     leg_d = np.abs(base["legs"][:, both] - var["legs"][:, both]).max() if both.any() else 0.0
+    per_track = np.abs(base["legs"][:, both] - var["legs"][:, both]).max(axis=(0, 2)) if both.any() else np.zeros(0)
     return {
         "disparity_pixels_changed": int(changed.sum()),
         "disparity_pixels_changed_frac_of_valid": float(changed.sum() / max(int(valid.sum()), 1)),
         "disparity_max_abs_change_16ths": int(np.abs(base["d16"].astype(np.int32) - var["d16"].astype(np.int32)).max()),
         "klt_status_changed": int((base["lst"] != var["lst"]).any(axis=0).sum()),
         "klt_max_track_change_px": float(leg_d),
+        "klt_tracks_compared": int(both.sum()),
+        "klt_tracks_moved_beyond_0.01px": int((per_track > 0.01).sum()),
+        "klt_tracks_moved_beyond_1px": int((per_track > 1.0).sum()),
         "matches": [int(base["n_matched"]), int(var["n_matched"])],
         "object_points": [int(base["n_obj"]), int(var["n_obj"])],
         "ransac_inliers": [int(base["inliers"]), int(var["inliers"])],

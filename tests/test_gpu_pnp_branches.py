@@ -52,6 +52,23 @@ def test_four_correspondences_use_the_three_point_solver():
     ctx.close()
 
 
+def test_four_correspondences_without_a_real_p3p_solution_report_ok_0():
+    """four collinear object points: P3P has no real solution.  The frame comes back with ok = 0 and the identity as [R|t]
+    (what the reference's zero-initialised rvec / tvec give when it ignores solvePnPRansac's return value,
+    Source/VOClass.cpp:531-566); a caller sees it in info.ok before integrating the pose."""
+    pts = [[100.0, 96.0], [240.0, 96.0], [380.0, 96.0], [520.0, 96.0]]
+    ctx, P0, obj, t2 = setup(lambda u, v: 5.0 + 0 * u, pts, np.zeros(3), np.array([0.0, 0.0, -0.8]))
+    t2_bad = t2.copy()
+    t2_bad[:, 1] += np.array([0.0, 40.0, -35.0, 60.0], dtype=np.float32)     # image points no pose of a line can produce
+    ctx.set_matches(np.asarray(pts, dtype=np.float32), t2_bad)
+    Rt, info = ctx.estimate_motion()
+    assert info[0].n_object_points == 4 and info[0].ok == 0 and info[0].best_inliers == 0
+    assert np.array_equal(Rt[0], np.eye(4))
+    ok, r, t, mask, oinfo = ob.solve_pnp_ransac(obj, t2_bad, P0, ob.default_params(W, H))
+    assert ok == 0
+    ctx.close()
+
+
 def test_three_correspondences_are_refused_like_the_original_throws():
     ctx, P0, obj, t2 = setup(lambda u, v: 10.0 + 0 * u, [[100, 40], [500, 60], [320, 150]], np.zeros(3), np.array([0, 0, -0.8]))
     with pytest.raises(abi.VoError) as e:

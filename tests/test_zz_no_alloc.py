@@ -21,14 +21,15 @@ def reference_corners(img, thr):
     return out
 
 
-def noalloc_corners(img, thr, cap):
+def noalloc_corners(img, thr, cap, stream=None):
     import torch
     h, w = img.shape
     d_img = torch.from_numpy(np.ascontiguousarray(img)).cuda()
     d_out = torch.full((cap, 2), -1.0, dtype=torch.float32, device="cuda")
     d_n = torch.full((1,), -1, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
-    rc = abi.lib().vo_detect_fast_noalloc(d_img.data_ptr(), w, h, w, thr, 1, d_out.data_ptr(), cap, d_n.data_ptr(), None)
+    rc = abi.lib().vo_detect_fast_noalloc(d_img.data_ptr(), w, h, w, thr, 1, d_out.data_ptr(), cap, d_n.data_ptr(),
+                                          C.c_void_p(stream.cuda_stream) if stream is not None else None)
     assert rc == 0, abi.lib().vo_create_error().decode()
     torch.cuda.synchronize()
     n = int(d_n.item())
@@ -43,6 +44,12 @@ def test_noalloc_fast_matches_the_context_entry_point_twice_in_a_row():
         assert len(want) > 100
         got, n = noalloc_corners(img, thr, 65536)
         assert n == len(want) and np.array_equal(got, want)
+    # on a stream of the caller's instead of the NULL stream
+    import torch
+    side = torch.cuda.Stream()
+    want = reference_corners(small, 12)
+    got, n = noalloc_corners(small, 12, 65536, stream=side)
+    assert n == len(want) and np.array_equal(got, want)
     # capacity smaller than the corner count: the first `cap` corners in row-major order, count clamped
     want = reference_corners(big, 20)
     got, n = noalloc_corners(big, 20, 500)

@@ -51,7 +51,7 @@ class Params(C.Structure):
         ("lk_epsilon", C.c_double), ("lk_min_eig", C.c_double),
         ("loop_threshold", C.c_int), ("depth_thresh", C.c_int),
         ("ransac_iters", C.c_int), ("ransac_reproj", C.c_float), ("ransac_conf", C.c_double),
-        ("ransac_chunk", C.c_int), ("host_threads", C.c_int),
+        ("ransac_chunk", C.c_int), ("host_threads", C.c_int), ("lk_accum", C.c_int),
     ]
 
 

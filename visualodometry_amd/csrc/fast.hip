@@ -12,6 +12,7 @@
 //                       mask words' popcounts gives every keypoint its rank, so the output order is y-major, x-minor,
 //                       identical on every run.
 #include "vo_ctx.h"
+#include <atomic>
 #include <string.h>
 #include <algorithm>
 #include <mutex>
@@ -224,10 +225,12 @@ int launch_fast(vo_ctx* c)
 }
 
 // ---------------------------------------------------------------- detection without any allocation
-// The same four kernels on one image, with their scratch (score map, per-row counts and offsets) in a fixed array of the
-// code object instead of a context's hipMalloc'ed buffers.  Every GPU the library runs on holds its own copy of the array
-// until the process ends.  In host code the array's name is only a handle for hipGetSymbolAddress: the address the
-// kernels get is looked up once per device, with that device current, and kept.
+// The same three kernels on one image, with their scratch (score map, per-row counts, keypoint flag words) in a fixed array
+// of the code object instead of a context's hipMalloc'ed buffers.  Every GPU the library runs on holds its own copy of the
+// array until the process ends.  In host code the array's name is only a handle for hipGetSymbolAddress: the address the
+// kernels get is looked up once per device, with that device current, and kept.  That look-up loads the code object and
+// takes a lock, which a stream capture does not allow: it happens in vo_create for the context's device, or in the first
+// call of the entry point on a device, so a caller that captures makes one of the two outside the capture first.
 constexpr size_t kNoAllocMaxPixels = (size_t)1 << 21;   // 2 Mi pixels (e.g. 1920 x 1080); KITTI frames are 0.47 Mi
 constexpr int kNoAllocMaxRows = 4096;
 constexpr size_t kNoAllocScoreBytes = kNoAllocMaxPixels;
@@ -238,7 +241,20 @@ constexpr size_t kNoAllocBytes = kNoAllocScoreBytes + kNoAllocCountBytes + kNoAl
 static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
 
 static std::mutex g_scratch_mu;
-static unsigned char* g_scratch_ptr[64]; // per device: address of that device's copy of `scratch`
+static std::atomic<unsigned char*> g_scratch_ptr[64]; // per device: address of that device's copy of `scratch`
+
+// Looks up the address of the CURRENT device's copy of the scratch array (dev = its index).  Not for use under stream capture.
+int vo_noalloc_prepare(int dev)
+{
+    if (dev < 0 || dev >= 64) return vo_fail(nullptr, VO_ERR_NO_DEVICE, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_ptr[dev].load(std::memory_order_relaxed)) return VO_OK;
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p) return vo_fail(nullptr, VO_ERR_HIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+    g_scratch_ptr[dev].store(static_cast<unsigned char*>(p), std::memory_order_release);
+    return VO_OK;
+}
 
 extern "C" int vo_detect_fast_noalloc(const uint8_t* img_dev, int width, int height, size_t stride, int threshold, int nms,
                                       vo_point2f* out_dev, int cap, int* n_out_dev, void* stream)
@@ -250,16 +266,11 @@ extern "C" int vo_detect_fast_noalloc(const uint8_t* img_dev, int width, int hei
                        width, height, kNoAllocMaxPixels, kNoAllocMaxRows);
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return vo_fail(nullptr, VO_ERR_NO_DEVICE, "no current HIP device");
-    unsigned char* base;
-    {
-        std::lock_guard<std::mutex> lk(g_scratch_mu);
-        if (!g_scratch_ptr[dev]) {
-            void* p = nullptr;
-            const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
-            if (e != hipSuccess || !p) return vo_fail(nullptr, VO_ERR_HIP, "hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
-            g_scratch_ptr[dev] = static_cast<unsigned char*>(p);
-        }
-        base = g_scratch_ptr[dev];
+    unsigned char* base = g_scratch_ptr[dev].load(std::memory_order_acquire);   // set once per device, never changed
+    if (!base) {
+        const int rc = vo_noalloc_prepare(dev);
+        if (rc != VO_OK) return rc;
+        base = g_scratch_ptr[dev].load(std::memory_order_acquire);
     }
     uint8_t* score = base;
     int* row_count = reinterpret_cast<int*>(base + kNoAllocScoreBytes);

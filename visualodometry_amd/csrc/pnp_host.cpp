@@ -829,11 +829,31 @@ std::mutex g_pool_mu;
 Pool* g_pool = nullptr;
 int g_pool_workers = 0;
 
-void parallel_for(vo_ctx*, int count, int threads, const std::function<void(int)>& fn)
+// The worker threads must not outlive the library's code: when the library is unloaded (or the process exits) the pool is
+// joined and deleted.
+__attribute__((destructor)) void destroy_pool()
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    delete g_pool;
+    g_pool = nullptr;
+    g_pool_workers = 0;
+}
+
+void parallel_for(vo_ctx* c, int count, int threads, const std::function<void(int)>& fn)
 {
     if (threads <= 1 || count <= 1) { for (int i = 0; i < count; i++) fn(i); return; }
     std::unique_lock<std::mutex> lk(g_pool_mu, std::try_to_lock);
-    if (!lk.owns_lock()) { for (int i = 0; i < count; i++) fn(i); return; }
+    if (!lk.owns_lock()) {
+        // another thread's section holds the pool: this one runs on the calling thread alone.  Counted, so that a caller
+        // who drives several contexts from several threads can see it in vo_get_timing (stage "pnp_host_serial").
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < count; i++) fn(i);
+        if (c && c->timing) {
+            c->stage_ms[VO_ST_PNP_SERIAL] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            c->stage_calls[VO_ST_PNP_SERIAL]++;
+        }
+        return;
+    }
     if (!g_pool || g_pool_workers < threads - 1) {
         delete g_pool;
         g_pool_workers = threads - 1;

@@ -64,6 +64,7 @@ static int derive(vo_ctx* c)
     if (p.wta_simd_lanes != 0 && p.wta_simd_lanes != 8 && p.wta_simd_lanes != 16) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "wta_simd_lanes must be 0, 8 or 16");
     if (p.lk_win < 3 || p.lk_win > 31 || !(p.lk_win & 1)) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "lk_win must be odd in [3, 31]");
     if (p.lk_max_level < 0 || p.lk_max_level >= VO_MAX_LEVELS) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "lk_max_level out of range");
+    if (p.lk_accum != 0) return vo_fail(nullptr, VO_ERR_UNSUPPORTED, "lk_accum %d: the tracker sums in exact integers (0); the float summation orders exist in the CPU oracle only", p.lk_accum);
     c->W = p.width; c->H = p.height; c->D = p.num_disparities; c->Dp = (c->D + 31) & ~31;
     c->width1 = c->W - c->D;
     if (c->width1 < 1) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "width must exceed num_disparities");
@@ -135,6 +136,7 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     if (rc != VO_OK) { delete c; return rc; }
 #define CR(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { vo_fail(nullptr, VO_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); vo_destroy(c); return VO_ERR_HIP; } } while (0)
     CR(hipSetDevice(device));
+    if (vo_noalloc_prepare(device) != VO_OK) { vo_destroy(c); return VO_ERR_HIP; } // so that vo_detect_fast_noalloc can be captured on this device
     CR(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     {
         // one high-priority stream per device for all contexts: a process has few hardware queues (4 by default), and
@@ -675,7 +677,7 @@ extern "C" int vo_step(vo_ctx* c, double* Rt_out, vo_frame_info* info)
 }
 
 static const char* kStageNames[VO_NUM_STAGES] = {"sgbm_prefilter", "", "sgbm_cost_vpath", "sgbm_hpath_ckpt", "sgbm_hpath_resolve",
-    "sgbm_lrcheck_median", "", "fast", "pyramid", "lk", "klt_filter", "triangulate", "pnp_score", "pnp_host", "step_wall", ""};
+    "sgbm_lrcheck_median", "", "fast", "pyramid", "lk", "klt_filter", "triangulate", "pnp_score", "pnp_host", "step_wall", "pnp_host_serial"};
 
 extern "C" const char* vo_stage_name(int s) { return s >= 0 && s < VO_NUM_STAGES ? kStageNames[s] : ""; }
 

@@ -151,6 +151,7 @@ int launch_fast(vo_ctx* c);
 int launch_sgbm(vo_ctx* c);
 int launch_depth_map(vo_ctx* c);
 int launch_depth_cloud(vo_ctx* c, int b, int* count);
+int vo_noalloc_prepare(int dev); // fast.hip: resolves the current device's scratch array of vo_detect_fast_noalloc
 int launch_pyramids(vo_ctx* c);
 int launch_match_klt(vo_ctx* c, bool counts_on_host);
 int launch_triangulate(vo_ctx* c);
