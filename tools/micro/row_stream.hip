@@ -1,0 +1,104 @@
+// What read rate do the access shapes of the horizontal-path kernels reach?  A [rows][cols][D] int16 cost volume (D = 96: 192 bytes
+// per column, 219 840 bytes per row at KITTI shape, rows far apart) is read once by
+//   v0  the shape of hpath_ckpt_kernel: a wavefront takes 4 rows, 16 lanes per row, 12 bytes per lane and column (dwordx3), 8 columns
+//       per group, next group requested while the current one is consumed;
+//   v1  the same rows per wavefront, but 16 bytes per lane: a 16-lane group reads 256 contiguous bytes of its row per instruction
+//       (6 instructions = 8 columns); the data would then need a transpose to the 12-bytes-per-lane compute layout;
+//   v2  one row per wavefront, 64 lanes x 16 bytes = 1 KiB contiguous per instruction (a plain stream);
+//   v3  v0 with 16 columns per group;
+//   v4  v1 with the group of 8 columns requested TWO groups ahead;
+// each with a trivial consumer (xor).  hipcc --offload-arch=gfx950 -O3 -o row_stream tools/micro/row_stream.hip && ./row_stream
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+
+typedef unsigned v3u __attribute__((ext_vector_type(3)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+constexpr int D = 96, COLS = 1145, ROW_BYTES = COLS * D * 2;
+
+template <int U>
+__global__ __launch_bounds__(256) void k_v0(const char* __restrict__ vol, int rows, unsigned* out)
+{
+    const int lane16 = threadIdx.x & 15, y = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (y >= rows) return;
+    const char* p = vol + (size_t)y * ROW_BYTES + lane16 * 12;
+    v3u cur[U], nxt[U], acc = {0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < U; u++) cur[u] = *reinterpret_cast<const v3u*>(p + (size_t)u * 192);
+    for (int x0 = 0; x0 < COLS; x0 += U) {
+        if (x0 + U < COLS)
+            for (int u = 0; u < U; u++) nxt[u] = *reinterpret_cast<const v3u*>(p + (size_t)min(x0 + U + u, COLS - 1) * 192);
+        for (int u = 0; u < U; u++) acc ^= cur[u];
+        for (int u = 0; u < U; u++) cur[u] = nxt[u];
+    }
+    if (acc.x == 0x12345 && acc.y == 77) out[threadIdx.x] = acc.z;
+}
+
+// 16 lanes x 16 bytes per row and instruction; a row is ROW_BYTES = 859 x 256 - 64 bytes: the last piece is clamped
+template <int AHEAD>
+__global__ __launch_bounds__(256) void k_v1(const char* __restrict__ vol, int rows, unsigned* out)
+{
+    constexpr int G = 6; // pieces of 256 bytes per group (= 8 columns)
+    const int lane16 = threadIdx.x & 15, y = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (y >= rows) return;
+    const char* p = vol + (size_t)y * ROW_BYTES + lane16 * 16;
+    const int pieces = (ROW_BYTES + 255) / 256;
+    v4u buf[AHEAD + 1][G], acc = {0, 0, 0, 0};
+    auto load = [&](int g, v4u (&b)[G]) {
+        for (int i = 0; i < G; i++) {
+            const int pc = min(g * G + i, pieces - 1);
+            size_t off = (size_t)pc * 256;
+            if (off + lane16 * 16 + 16 > (size_t)ROW_BYTES) off = 0;
+            b[i] = *reinterpret_cast<const v4u*>(p + off);
+        }
+    };
+    const int groups = (pieces + G - 1) / G;
+    for (int a = 0; a < AHEAD; a++) load(a, buf[a]);
+    for (int g = 0; g < groups; g++) {
+        if (g + AHEAD < groups) load(g + AHEAD, buf[AHEAD]);
+        for (int i = 0; i < G; i++) acc ^= buf[0][i];
+        for (int a = 0; a < AHEAD; a++)
+            for (int i = 0; i < G; i++) buf[a][i] = buf[a + 1][i];
+    }
+    if (acc.x == 0x12345 && acc.y == 77) out[threadIdx.x] = acc.z;
+}
+
+__global__ __launch_bounds__(256) void k_v2(const char* __restrict__ vol, int rows, unsigned* out)
+{
+    const int lane = threadIdx.x & 63, y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (y >= rows) return;
+    const char* p = vol + (size_t)y * ROW_BYTES + lane * 16;
+    const int pieces = ROW_BYTES / 1024;
+    v4u acc = {0, 0, 0, 0};
+    for (int i = 0; i < pieces; i += 4) {
+        v4u t[4];
+        for (int k = 0; k < 4; k++) t[k] = *reinterpret_cast<const v4u*>(p + (size_t)min(i + k, pieces - 1) * 1024);
+        for (int k = 0; k < 4; k++) acc ^= t[k];
+    }
+    if (acc.x == 0x12345 && acc.y == 77) out[threadIdx.x] = acc.z;
+}
+
+int main()
+{
+    const int rows = 42 * 376;
+    const size_t bytes = (size_t)rows * ROW_BYTES;
+    char* vol; unsigned* out;
+    if (hipMalloc(&vol, bytes + 4096) != hipSuccess || hipMalloc(&out, 4096) != hipSuccess) return 1;
+    (void)hipMemset(vol, 1, bytes + 4096);
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    auto run = [&](const char* name, auto launch) {
+        launch(); (void)hipDeviceSynchronize();
+        (void)hipEventRecord(e0);
+        for (int r = 0; r < 5; r++) launch();
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        printf("%-64s %7.1f GB/s  %.3f ms\n", name, 5 * (double)bytes / (ms * 1e-3) / 1e9, ms / 5);
+    };
+    run("v0 4 rows/wave, dwordx3 per column, 8 columns ahead", [&] { hipLaunchKernelGGL(k_v0<8>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out); });
+    run("v3 4 rows/wave, dwordx3 per column, 16 columns ahead", [&] { hipLaunchKernelGGL(k_v0<16>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out); });
+    run("v1 4 rows/wave, 256 B per row and instruction, 1 group ahead", [&] { hipLaunchKernelGGL(k_v1<1>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out); });
+    run("v4 4 rows/wave, 256 B per row and instruction, 2 groups ahead", [&] { hipLaunchKernelGGL(k_v1<2>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out); });
+    run("v2 1 row/wave, 1 KiB per instruction", [&] { hipLaunchKernelGGL(k_v2, dim3((rows + 3) / 4), dim3(256), 0, 0, vol, rows, out); });
+    return 0;
+}

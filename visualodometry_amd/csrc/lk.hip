@@ -165,6 +165,7 @@ __device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int
 // row once.  Pixels are kept as 16-bit pairs (p[x], p[x+1]) and weights as 16-bit pairs, so one bilinear sample
 // is two v_dot2_i32_i16; the rounding constant and the template value ride in the accumulator operand:
 //     diff = (J00*w00 + J01*w01 + J10*w10 + J11*w11 + 2^8 - (I << 9)) >> 9        (exact: I << 9 is a multiple of 2^9)
+// The second product of a sample reads its pixel pairs from the next lane through the DPP form of the accumulating dot product.
 // The mismatch vector uses dot2 on pairs of diffs against pairs of Ix (Iy).  Sums are integers, so the order of
 // accumulation is free; the 16-lane reduction is 4 DPP row adds on 16-bit halves, recombined exactly in f64.
 typedef short lk_v2s __attribute__((ext_vector_type(2)));
@@ -178,8 +179,31 @@ __device__ __forceinline__ int dot2_keep(int a, int b, int c)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_v2s, a), __builtin_bit_cast(lk_v2s, b), c, true);
 }
-// lane i takes lane i+1's value; the last lane of a group gets 0 (it owns no live window row that needs it)
-__device__ __forceinline__ int from_next_lane(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xF, 0xF, true); }
+// acc[i] += dot2(src[i] of the NEXT lane, w) for i in [I0, I0 + 5): the DPP form of the accumulating dot product reads its first
+// operand from the neighbouring lane directly (row_shl:1: lane i takes lane i + 1's value, 0 for the last lane of a row of 16,
+// which owns no live window row that needs it), which saves the separate cross-lane move per operand.  The compiler does not form this instruction itself, hence the assembly.  A DPP operand written by the vector
+// instruction just before it needs two idle issue slots: the leading s_nop provides them whatever was scheduled before the
+// block (the hazard logic does not look inside assembly text).
+template <int N, int I0>
+__device__ __forceinline__ void dot2c_next_lane(int (&acc)[N], const int (&src)[N], int w)
+{
+    if constexpr (I0 + 5 <= N) {
+        asm("s_nop 1\n\t"
+            "v_dot2c_i32_i16_dpp %0, %5, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_dot2c_i32_i16_dpp %1, %6, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_dot2c_i32_i16_dpp %2, %7, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_dot2c_i32_i16_dpp %3, %8, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_dot2c_i32_i16_dpp %4, %9, %10 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+            : "+v"(acc[I0]), "+v"(acc[I0 + 1]), "+v"(acc[I0 + 2]), "+v"(acc[I0 + 3]), "+v"(acc[I0 + 4])
+            : "v"(src[I0]), "v"(src[I0 + 1]), "v"(src[I0 + 2]), "v"(src[I0 + 3]), "v"(src[I0 + 4]), "v"(w));
+        dot2c_next_lane<N, I0 + 5>(acc, src, w);
+    } else if constexpr (I0 < N) {
+        asm("s_nop 1\n\t"
+            "v_dot2c_i32_i16_dpp %0, %1, %2 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+            : "+v"(acc[I0]) : "v"(src[I0]), "v"(w));
+        dot2c_next_lane<N, I0 + 1>(acc, src, w);
+    }
+}
 __device__ __forceinline__ int pack_lo16(int lo, int hi) { return (int)__builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u); }
 
 // (lo >> 9, hi >> 9) as packed 16-bit halves, for |lo|, |hi| < 2^23
@@ -326,28 +350,39 @@ __global__ __launch_bounds__(LK_THREADS) void lk_row_kernel(LkArgs a, const uint
                 const int w0 = (w00 & 0xffff) | (w01 << 16), w1 = (w10 & 0xffff) | (w11 << 16);
                 const uint8_t* I = Ibase + L.img_off + (size_t)(ipy + a.pa.border) * P + (ipx + a.pa.border);
                 const int* Dv = reinterpret_cast<const int*>(Dbase + L.der_off) + (size_t)(ipy + a.pa.border) * P + (ipx + a.pa.border);
-                int pr[NR + 1][NPX], dx[NR + 1][NPX], dy[NR + 1][NPX];
+                int pr[NR][NPX], dx[NR][NPX], dy[NR][NPX];
 #pragma unroll
                 for (int k = 0; k < NR; k++) {
                     pixel_pairs<NDW>(I + rowoff[k], pr[k]);
                     deriv_pairs<NDW>(Dv + rowoff[k], dx[k], dy[k]);
-                }
-#pragma unroll
-                for (int x = 0; x < NPX; x++) {
-                    pr[NR][x] = from_next_lane(pr[0][x]); dx[NR][x] = from_next_lane(dx[0][x]); dy[NR][x] = from_next_lane(dy[0][x]);
                 }
                 int s11 = 0, s12 = 0, s22 = 0;
 #pragma unroll
                 for (int k = 0; k < NR; k++) {
                     const bool live = row0 + k < win;
                     const int wd0 = live ? w0 : 0, wd1 = live ? w1 : 0; // a dead row gets zero derivatives
-                    int ixv[NPX + 1], iyv[NPX + 1];
+                    int ivv[NPX], ixv[NPX + 1], iyv[NPX + 1];
 #pragma unroll
                     for (int x = 0; x < NPX; x++) {
-                        const int iv = dot2(pr[k + 1][x], w1, dot2_keep(pr[k][x], w0, 1 << 8)) >> 9;
-                        C0[k][x] = (1 << 8) - (iv << 9);
-                        ixv[x] = dot2(dx[k + 1][x], wd1, dot2_keep(dx[k][x], wd0, 1 << 13)) >> 14;
-                        iyv[x] = dot2(dy[k + 1][x], wd1, dot2_keep(dy[k][x], wd0, 1 << 13)) >> 14;
+                        ivv[x] = dot2_keep(pr[k][x], w0, 1 << 8);
+                        ixv[x] = dot2_keep(dx[k][x], wd0, 1 << 13);
+                        iyv[x] = dot2_keep(dy[k][x], wd0, 1 << 13);
+                    }
+                    // the source row below a lane's last window row is the next lane's first row
+                    if (k + 1 < NR) {
+#pragma unroll
+                        for (int x = 0; x < NPX; x++) {
+                            ivv[x] = dot2(pr[k + 1][x], w1, ivv[x]); ixv[x] = dot2(dx[k + 1][x], wd1, ixv[x]); iyv[x] = dot2(dy[k + 1][x], wd1, iyv[x]);
+                        }
+                    } else {
+                        dot2c_next_lane<NPX, 0>(ivv, pr[0], w1);
+                        dot2c_next_lane<NPX, 0>(reinterpret_cast<int (&)[NPX]>(ixv), dx[0], wd1);
+                        dot2c_next_lane<NPX, 0>(reinterpret_cast<int (&)[NPX]>(iyv), dy[0], wd1);
+                    }
+#pragma unroll
+                    for (int x = 0; x < NPX; x++) {
+                        C0[k][x] = (1 << 8) - ((ivv[x] >> 9) << 9);
+                        ixv[x] >>= 14; iyv[x] >>= 14;
                     }
                     ixv[NPX] = 0; iyv[NPX] = 0;
 #pragma unroll
@@ -383,17 +418,23 @@ __global__ __launch_bounds__(LK_THREADS) void lk_row_kernel(LkArgs a, const uint
                         bilinear_weights(qx - inx, qy - iny, w00, w01, w10, w11);
                         const int w0 = (w00 & 0xffff) | (w01 << 16), w1 = (w10 & 0xffff) | (w11 << 16);
                         const uint8_t* J = Jl + (iny * P + inx); // a level is far below 2^31 bytes: 32-bit offset arithmetic
-                        int pr[NR + 1][NPX];
+                        int pr[NR][NPX];
 #pragma unroll
                         for (int k = 0; k < NR; k++) pixel_pairs<NDW>(J + rowoff[k], pr[k]);
-#pragma unroll
-                        for (int x = 0; x < NPX; x++) pr[NR][x] = from_next_lane(pr[0][x]);
                         int sb1 = 0, sb2 = 0;
 #pragma unroll
                         for (int k = 0; k < NR; k++) {
                             int d[NPX + 1];
+                            // the source row below a lane's last window row is the next lane's first row
 #pragma unroll
-                            for (int x = 0; x < NPX; x++) d[x] = dot2(pr[k + 1][x], w1, dot2_keep(pr[k][x], w0, C0[k][x]));
+                            for (int x = 0; x < NPX; x++) d[x] = dot2_keep(pr[k][x], w0, C0[k][x]);
+                            if (k + 1 < NR) {
+#pragma unroll
+                                for (int x = 0; x < NPX; x++) d[x] = dot2(pr[k + 1][x], w1, d[x]);
+                            } else {
+                                int (&dd)[NPX] = reinterpret_cast<int (&)[NPX]>(d);
+                                dot2c_next_lane<NPX, 0>(dd, pr[0], w1);
+                            }
                             d[NPX] = 0;
 #pragma unroll
                             for (int p = 0; p < NPP; p++) {

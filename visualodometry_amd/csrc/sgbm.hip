@@ -493,15 +493,18 @@ __global__ __launch_bounds__(256) void hpath_ckpt_kernel(const int16_t* __restri
 #pragma unroll
     for (int k = 0; k < NP; k++) Lp[k] = splat(0);
     int m = 0;
-    constexpr int U = 8;
-    v2s cur[U][NP], nxt[U][NP];
+    // Columns are consumed in groups of U, and a group is requested TWO groups before it is consumed: the kernel runs at
+    // memory speed, where a request takes several microseconds to come back, longer than one group's arithmetic.  Three
+    // register groups take turns (the loop body is written out three times so that no group is ever copied).
+    constexpr int U = NP >= 5 ? 4 : 8; // 3 U NP registers hold the groups
+    v2s g0[U][NP], g1[U][NP], g2[U][NP];
     auto load_group = [&](int x0, v2s (&g)[U][NP]) {
+        if (x0 >= width1) return; // uniform
 #pragma unroll
         for (int u = 0; u < U; u++) load_pk<NP>(Cp + (size_t)min(x0 + u, width1 - 1) * D, g[u]);
     };
-    load_group(0, cur);
-    for (int x0 = 0; x0 < width1; x0 += U) {
-        if (x0 + U < width1) load_group(x0 + U, nxt);
+    auto process = [&](int x0, v2s (&g)[U][NP]) {
+        if (x0 >= width1) return; // uniform
         if ((x0 % HP_SEG) == 0 && active) { // state before column x0
             int* q = ck + (size_t)(x0 / HP_SEG) * 16 * (NP + 1);
 #pragma unroll
@@ -510,11 +513,14 @@ __global__ __launch_bounds__(256) void hpath_ckpt_kernel(const int16_t* __restri
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
-            if (x0 + u < width1) m = path_step<NP>(cur[u], Lp, m, P1, P2, inf_pk);
-#pragma unroll
-        for (int u = 0; u < U; u++)
-#pragma unroll
-            for (int k = 0; k < NP; k++) cur[u][k] = nxt[u][k];
+            if (x0 + u < width1) m = path_step<NP>(g[u], Lp, m, P1, P2, inf_pk);
+    };
+    load_group(0, g0);
+    load_group(U, g1);
+    for (int x0 = 0; x0 < width1; x0 += 3 * U) {
+        load_group(x0 + 2 * U, g2); process(x0, g0);
+        load_group(x0 + 3 * U, g0); process(x0 + U, g1);
+        load_group(x0 + 4 * U, g1); process(x0 + 2 * U, g2);
     }
 }
 
@@ -561,12 +567,15 @@ __global__ __launch_bounds__(64, (NP >= 7 ? 2 : 1)) void hpath_resolve_kernel(co
 #pragma unroll
         for (int k = 0; k <= NP; k++) c[k] = q[k];
     };
+    // (the widest ranges have no register to spare for a request that overlaps the winner search: they ask at the top of a segment)
+    constexpr bool T_EARLY = NP <= 6;
     load_seg(Cp, nseg - 1, Cc);
     load_ck(nseg - 1, ckc);
+    if (T_EARLY) load_seg(Tp, nseg - 1, Tt);
     for (int s = nseg - 1; s >= 0; s--) {
         const int x0 = s * HP_SEG;
         const int cols = min(HP_SEG, width1 - x0);
-        load_seg(Tp, s, Tt);
+        if (!T_EARLY) load_seg(Tp, s, Tt);
         // replay L_lr over the segment
         v2s Lp[NP];
 #pragma unroll
@@ -593,6 +602,10 @@ __global__ __launch_bounds__(64, (NP >= 7 ? 2 : 1)) void hpath_resolve_kernel(co
                     trow[u * STR + lane16 * NP + k] = lane16 * 2 * NP + 2 * k >= D ? 0x7fff7fff : sum;
                 }
             }
+            // column u of L_top has had its last use: its registers take the same column of the NEXT segment now, so that the
+            // request has the rest of this loop, the winner search and the next replay to come back (a request made at the top
+            // of the next segment had the replay alone, which is shorter than a trip to memory at full bandwidth)
+            if (T_EARLY && s > 0) load_cols(Tp, s - 1, Tt, u, u + 1);
         }
         if (s > 0) load_cols(Cp, s - 1, Cn, HP_SEG / 2, HP_SEG);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // same-wavefront exchange: program order in the LDS queue is enough
