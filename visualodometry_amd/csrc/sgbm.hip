@@ -233,7 +233,15 @@ struct CostTile {
     static constexpr int RSLOTS = RPX + RPX / 16;           // with the pad slots
     static constexpr int EVAL_SLOTS = RSLOTS + CV_COLS;     // + the left pixels
     static constexpr int ENTRIES = RPX + CV_COLS;           // pixels fetched per row evaluation
-    static constexpr size_t lds_bytes() { return (size_t)2 * CV_COLS * CS * 4 + (size_t)2 * 2 * EVAL_SLOTS * 8; }
+    // Planar staging (4 columns per lane group): the six prefiltered values of a pixel go to six planes of 16-bit slots, the
+    // right pixels of a tile in DESCENDING image order followed by the left pixels in ascending order.  Two adjacent slots
+    // of a right plane are then the operands of two adjacent disparities (x - d and x - d - 1) as one packed register, read
+    // straight from LDS or formed by one alignbit, and a left value is a half of a register that the packed instructions
+    // select by themselves: the cost evaluation needs no byte extraction at all.
+    static constexpr bool PLANAR = NCOL_ == 4;
+    static constexpr int PSTR = (RPX + CV_COLS) * 2;        // bytes per plane
+    static constexpr int EVAL_BYTES = PLANAR ? 6 * PSTR : EVAL_SLOTS * 8;
+    static constexpr size_t lds_bytes() { return (size_t)2 * CV_COLS * CS * 4 + (size_t)2 * 2 * EVAL_BYTES; }
 };
 
 template <int NP, int SWC, int NCOL_>
@@ -264,6 +272,7 @@ __global__ __launch_bounds__((CostTile<NP, NCOL_>::THREADS), 4) void cost_vpath_
     // then right pixels x0 - D + m (m < RPX) and left pixels x0 + m - RPX.  Pixels outside the image are never used.
     const int x0 = minX1 + xc0; // image column of tile column 0
     int st_slot[2]; unsigned st_off[2]; bool st_enter[2];
+    char* const stage_b = reinterpret_cast<char*>(stage);
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int n = (int)threadIdx.x + u * T::THREADS;
@@ -271,6 +280,9 @@ __global__ __launch_bounds__((CostTile<NP, NCOL_>::THREADS), 4) void cost_vpath_
         const bool right = mm < T::RPX;
         const int x = right ? x0 - D + mm : x0 + (mm - T::RPX);
         st_enter[u] = e == 1;
+        if (T::PLANAR) // byte offset of the pixel's slot in the first plane of its evaluation
+            st_slot[u] = n < 2 * T::ENTRIES ? e * T::EVAL_BYTES + 2 * (right ? T::RPX - 1 - mm : mm) : -1;
+        else
         st_slot[u] = n < 2 * T::ENTRIES ? e * T::EVAL_SLOTS + (right ? mm + (mm >> 4) : T::RSLOTS + (mm - T::RPX)) : -1;
         // byte offset inside the frame's two images; anything not addressable becomes "far out of range" (reads 0)
         st_off[u] = (n < 2 * T::ENTRIES && x >= 0 && x < Wp) ? (right ? img_bytes : 0u) + 8u * (unsigned)x : 0xC0000000u;
@@ -283,7 +295,16 @@ __global__ __launch_bounds__((CostTile<NP, NCOL_>::THREADS), 4) void cost_vpath_
     };
     auto publish = [&](int buf) {
 #pragma unroll
-        for (int u = 0; u < 2; u++) if (st_slot[u] >= 0) stage[buf * 2 * T::EVAL_SLOTS + st_slot[u]] = pf[u];
+        for (int u = 0; u < 2; u++) if (st_slot[u] >= 0) {
+            if constexpr (T::PLANAR) {
+                // byte stores into the low halves of the 16-bit slots; the high halves were zeroed once and stay zero
+                uint8_t* q = reinterpret_cast<uint8_t*>(stage_b + buf * 2 * T::EVAL_BYTES + st_slot[u]);
+                const unsigned a = pf[u].x, c = pf[u].y;
+                q[0] = (uint8_t)a; q[T::PSTR] = (uint8_t)(a >> 8); q[2 * T::PSTR] = (uint8_t)(a >> 16);
+                q[3 * T::PSTR] = (uint8_t)c; q[4 * T::PSTR] = (uint8_t)(c >> 8); q[5 * T::PSTR] = (uint8_t)(c >> 16);
+            } else
+                stage[buf * 2 * T::EVAL_SLOTS + st_slot[u]] = pf[u];
+        }
     };
 
     v2s V[NCOL][NP], Lp[NCOL][NP];
@@ -329,7 +350,50 @@ __global__ __launch_bounds__((CostTile<NP, NCOL_>::THREADS), 4) void cost_vpath_
     // the same from the staged pixels of evaluation e in stage buffer `buf`
     const int p0 = cb + 2 * NP * (15 - lane16) + 1;   // index of the lane's first right pixel among the tile's RPX
     const int p0_slot = p0 + (p0 >> 4), p0_wrap = 16 - (p0 & 15); // from its p0_wrap-th pixel on, one pad slot lies between
+    // the same from the planes: window of the lane's right pixels p0 .. p0 + NR - 1 (stored descending: pixel p0 + i sits in 16-bit
+    // slot NR - 1 - i of the window, which starts on a dword), so the pair (pixel of disparity 2k, pixel of disparity 2k + 1) of
+    // column j is slots (o, o + 1) with o = NCOL - 1 + 2k - j: a whole dword when o is even, one alignbit when it is odd
+    auto accum_planar = [&](int buf, int e, int sign) {
+        constexpr int WN = NP + NCOL / 2, HC = NCOL / 2;
+        const char* S = stage_b + (buf * 2 + e) * T::EVAL_BYTES;
+        const int win_b = 2 * (T::RPX - 1 - p0 - (NR - 1));
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) { // 0: clipped gradient, 1: raw intensity (its cost counts a quarter)
+            int Wd[3][WN], L[3][HC], A[3][WN - 1];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++) {
+                __builtin_memcpy(Wd[pl], S + (ch * 3 + pl) * T::PSTR + win_b, 4 * WN);
+                __builtin_memcpy(L[pl], S + (ch * 3 + pl) * T::PSTR + 2 * (T::RPX + cb), 4 * HC);
+#pragma unroll
+                for (int t = 0; t + 1 < WN; t++) A[pl][t] = (int)__builtin_amdgcn_alignbit((unsigned)Wd[pl][t + 1], (unsigned)Wd[pl][t], 16);
+            }
+#pragma unroll
+            for (int j = 0; j < NCOL; j++) {
+                v2s lu[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) {
+                    const v2s t = as_v2s(L[pl][j >> 1]);
+                    lu[pl] = (j & 1) ? __builtin_shufflevector(t, t, 1, 1) : __builtin_shufflevector(t, t, 0, 0);
+                }
+#pragma unroll
+                for (int k = 0; k < NP; k++) {
+                    const int o = NCOL - 1 + 2 * k - j;
+                    v2s rv[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; pl++) rv[pl] = as_v2s((o & 1) ? A[pl][o >> 1] : Wd[pl][o >> 1]);
+                    const v2s c0 = as_v2s(as_int(sub_sat0(lu[0], rv[2])) | as_int(sub_sat0(rv[1], lu[0])));
+                    const v2s c1 = as_v2s(as_int(sub_sat0(rv[0], lu[2])) | as_int(sub_sat0(lu[1], rv[0])));
+                    v2s c = vmin(c0, c1);
+                    if (ch == 1) c = c >> 2;
+                    // no carry or borrow crosses the halves (see add_cost): plain 32-bit adds
+                    V[j][k] = as_v2s(sign > 0 ? as_int(V[j][k]) + as_int(c) : as_int(V[j][k]) - as_int(c));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0); // one channel's operands live at a time
+        }
+    };
     auto accum_staged = [&](int buf, int e, int scale) {
+        if constexpr (T::PLANAR) { accum_planar(buf, e, scale); return; }
         const v2u32* S = stage + (buf * 2 + e) * T::EVAL_SLOTS;
         v2u32 r[NR], l[NCOL];
 #pragma unroll
@@ -349,6 +413,10 @@ __global__ __launch_bounds__((CostTile<NP, NCOL_>::THREADS), 4) void cost_vpath_
         m[j] = 0;
 #pragma unroll
         for (int k = 0; k < NP; k++) { V[j][k] = splat(0); Lp[j][k] = splat(0); }
+    }
+    if constexpr (T::PLANAR) { // the high halves of the 16-bit slots stay zero for the whole kernel
+        for (int i = threadIdx.x; i < 2 * 2 * T::EVAL_BYTES / 4; i += T::THREADS) reinterpret_cast<int*>(stage_b)[i] = 0;
+        __syncthreads();
     }
     // rows above the stripe top repeat its first row; past the last image row the last row repeats
     if (rows > 1) prefetch(y0, min(y0 + 1 + SW2, H - 1)); // row 1: row 0 of the stripe leaves (it stood in for the rows above), row 1 + SW2 enters
