@@ -216,9 +216,10 @@ int vo_step(vo_ctx* ctx, double* Rt_out /* n*16 */, vo_frame_info* info /* nulla
  * vo_step(ctx, ...) == vo_step_submit(ctx) followed by vo_step_finish(ctx, ...).
  * Streams: a context enqueues on one stream of its own; the pose solver's short round trips use one
  * high-priority stream shared by all contexts of a device.  A process has few hardware queues (4 unless
- * GPU_MAX_HW_QUEUES says otherwise), so three contexts in flight is the sweet spot for throughput.  With the
- * environment variable VO_DUAL_STREAM set when a context is created, the corner / tracking chain of a step
- * runs on a second stream beside the disparity chain: lower latency for a single context, no gain with three. */
+ * GPU_MAX_HW_QUEUES says otherwise), so three contexts in flight is the sweet spot for throughput.  A step of ONE frame
+ * pair runs its corner / tracking chain on a second stream beside the disparity chain (a single pair leaves most of the
+ * GPU idle: 2.2 -> 1.8 ms per step at KITTI shape); batches do that only with the environment variable VO_DUAL_STREAM set
+ * when the context is created (no gain with three contexts in flight), and VO_SINGLE_STREAM turns it off altogether. */
 int vo_step_submit(vo_ctx* ctx);
 int vo_step_finish(vo_ctx* ctx, double* Rt_out /* n*16 */, vo_frame_info* info /* nullable, n */);
 

@@ -873,6 +873,7 @@ struct FrameRansac {
     std::vector<uint8_t> best_mask;
     int nh = 0;                // hypotheses in the current round
     std::vector<std::array<double, 3>> hr, ht; // the round's rvec / tvec, `ransac_chunk` of them
+    std::vector<std::array<int, 5>> idx;       // ... and the subsets they were solved from
     int best_h = -1;           // hypothesis of this round that became the best model
 };
 
@@ -914,7 +915,7 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
         FrameRansac& f = fr[b];
         f.k = k; f.obj = objs[b].data(); f.img = imgs[b].data();
         f.niters = std::max(c->p.ransac_iters, 1);
-        f.hr.resize(chunk); f.ht.resize(chunk);
+        f.hr.resize(chunk); f.ht.resize(chunk); f.idx.resize(chunk);
         if (k < 4) { f.failed = true; status = VO_ERR_NOT_ENOUGH_POINTS; } // the original asserts at least 4 points
         else if (k == 4 || k == model_points) f.direct = true;          // no sampling: one minimal solve on all points
         else f.active = true;
@@ -931,25 +932,32 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
         bool any = false;
         for (int b = 0; b < n; b++) any = any || (fr[b].active && fr[b].iter < fr[b].niters);
         if (!any) break;
-        // minimal solver on the host: the next `chunk` subsets of every frame still iterating
-        parallel_for(c, n, threads, [&](int b) {
+        // minimal solver on the host: the next `chunk` subsets of every frame still iterating.  The subsets come off each
+        // frame's generator in order (a cheap serial pass); the solves are independent and are spread over the worker threads
+        // one (frame, hypothesis) at a time, so that a batch of one frame uses the threads as well as a batch of forty.
+        for (int b = 0; b < n; b++) {
             FrameRansac& f = fr[b];
             f.nh = 0; f.best_h = -1;
-            if (!f.active || f.iter >= f.niters) return;
+            if (!f.active || f.iter >= f.niters) continue;
             f.nh = std::min(chunk, f.niters - f.iter);
-            for (int h = 0; h < f.nh; h++) {
-                int idx[5];
-                draw_subset(f.rng, f.k, model_points, idx);
-                vo_point3f so[5]; vo_point2f si[5];
-                for (int j = 0; j < 5; j++) { so[j] = f.obj[idx[j]]; si[j] = f.img[idx[j]]; }
-                epnp(so, si, 5, K, f.hr[h].data(), f.ht[h].data());
-                double R[9];
-                rodrigues_to_matrix(f.hr[h].data(), R, nullptr);
-                double* dst = h_hyp + ((size_t)b * chunk + h) * 12;
-                memcpy(dst, R, sizeof(R)); dst[9] = f.ht[h][0]; dst[10] = f.ht[h][1]; dst[11] = f.ht[h][2];
-            }
-            for (int h = f.nh; h < chunk; h++) memcpy(h_hyp + ((size_t)b * chunk + h) * 12, h_hyp + ((size_t)b * chunk) * 12, 12 * sizeof(double));
+            for (int h = 0; h < f.nh; h++) draw_subset(f.rng, f.k, model_points, f.idx[h].data());
+        }
+        parallel_for(c, n * chunk, threads, [&](int t) {
+            const int b = t / chunk, h = t - b * chunk;
+            FrameRansac& f = fr[b];
+            double* dst = h_hyp + ((size_t)b * chunk + h) * 12;
+            if (h >= f.nh) return;
+            vo_point3f so[5]; vo_point2f si[5];
+            for (int j = 0; j < 5; j++) { so[j] = f.obj[f.idx[h][j]]; si[j] = f.img[f.idx[h][j]]; }
+            epnp(so, si, 5, K, f.hr[h].data(), f.ht[h].data());
+            double R[9];
+            rodrigues_to_matrix(f.hr[h].data(), R, nullptr);
+            memcpy(dst, R, sizeof(R)); dst[9] = f.ht[h][0]; dst[10] = f.ht[h][1]; dst[11] = f.ht[h][2];
         });
+        // slots beyond a frame's hypotheses repeat its first one (scored and ignored; an idle frame's slots are never read)
+        for (int b = 0; b < n; b++)
+            for (int h = fr[b].nh; h < chunk && fr[b].nh > 0; h++)
+                memcpy(h_hyp + ((size_t)b * chunk + h) * 12, h_hyp + ((size_t)b * chunk) * 12, 12 * sizeof(double));
         // GPU: score every hypothesis of every frame against all of that frame's correspondences
         VO_HIP(c, hipMemcpyAsync(c->hyp, h_hyp, (size_t)n * chunk * 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
         int rc = launch_pnp_score(c, 0, n, chunk, thresh2, true);

@@ -150,7 +150,9 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
         c->stream_hi = g_hi_stream[device];
         g_hi_users[device]++;
     }
+    c->single_stream = getenv("VO_SINGLE_STREAM") != nullptr;
     if (getenv("VO_DUAL_STREAM")) {
+        c->dual_always = true;
         CR(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         CR(hipEventCreateWithFlags(&c->join2, hipEventDisableTiming));
     }
@@ -627,12 +629,20 @@ extern "C" int vo_step_submit(vo_ctx* c)
     c->have_disp = true; c->have_depth = false;
     // disparity and the corner / tracking chain are independent until triangulation: with a second stream the
     // instruction-bound tracker runs beside the bandwidth-bound cost volume passes of the same batch
+    // A single frame pair leaves most of the GPU idle (its kernels are serial along x or y): there the second stream is
+    // always worth it (2.2 -> 1.8 ms per step at KITTI shape) and is created on first use.  Batches fill the GPU by
+    // themselves and use it only on request (VO_DUAL_STREAM).
+    if (!c->stream2 && c->n == 1 && !c->single_stream) {
+        VO_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        VO_HIP(c, hipEventCreateWithFlags(&c->join2, hipEventDisableTiming));
+    }
     hipStream_t main_stream = c->stream;
-    if (c->stream2) c->stream = c->stream2;
+    const bool dual = c->stream2 && (c->n == 1 || c->dual_always);
+    if (dual) c->stream = c->stream2;
     rc = launch_fast(c);
     if (!rc) rc = launch_pyramids(c);
     if (!rc) { c->have_pyr = true; rc = launch_match_klt(c, false); }
-    if (c->stream2) {
+    if (dual) {
         if (!rc && hipEventRecord(c->join2, c->stream2) != hipSuccess) rc = vo_fail(c, VO_ERR_HIP, "hipEventRecord failed");
         c->stream = main_stream;
         if (!rc && hipStreamWaitEvent(c->stream, c->join2, 0) != hipSuccess) rc = vo_fail(c, VO_ERR_HIP, "hipStreamWaitEvent failed");

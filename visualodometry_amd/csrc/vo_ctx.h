@@ -27,6 +27,7 @@ struct vo_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // optional: corner / tracking chain of a step, beside the disparity chain on `stream`
     hipEvent_t join2 = nullptr;
+    bool dual_always = false, single_stream = false; // VO_DUAL_STREAM: second stream for every batch size; VO_SINGLE_STREAM: never
     hipStream_t stream_hi = nullptr; // highest priority: the short scoring round trips of the pose solver
     std::string err;
 
