@@ -723,7 +723,8 @@ def main(argv=None):
                 traffic = tj.get(wk, {}).get(dom)
                 if traffic is not None:  # bytes scale with the frames of a launch
                     traffic = traffic * B / cb
-                traffic_per_frame = sum(v for v in tj.get(wk, {}).values() if isinstance(v, (int, float))) / cb
+                allk = tj.get(wk + "_all_kernels")   # every kernel of the path; older files hold the large kernels only
+                traffic_per_frame = (allk if allk else sum(v for v in tj.get(wk, {}).values() if isinstance(v, (int, float)))) / cb
             except Exception:
                 traffic = None
 

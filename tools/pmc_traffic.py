@@ -28,10 +28,13 @@ def short(name):
     return base
 
 
-def per_kernel(path):
+def per_kernel(path, totals=None):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    if totals is not None:   # sum over every dispatch, and how often a once-per-step kernel ran
+        totals["sum"] = sum(sum(v) for v in acc.values())
+        totals["steps"] = len(acc.get("cost_vpath_kernel", [])) or 1
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
 
@@ -39,7 +42,8 @@ def main():
     workload, fetch_csv, write_csv = sys.argv[1:4]
     tag = sys.argv[4] if len(sys.argv) > 4 else ""
     batch = int(sys.argv[5]) if len(sys.argv) > 5 else (8 if workload == "4k" else 16)
-    F, W = per_kernel(fetch_csv), per_kernel(write_csv)
+    tf, tw = {}, {}
+    F, W = per_kernel(fetch_csv, tf), per_kernel(write_csv, tw)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out_path = os.path.join(root, "profiles", "traffic.json")
     data = json.load(open(out_path)) if os.path.exists(out_path) else {}
@@ -51,6 +55,9 @@ def main():
             entry[STAGE[k]] = fetch + write
     data[workload] = entry
     data[workload + "_batch"] = batch
+    # every kernel of the path, the small ones included: what the whole path moves per launch of one batch
+    # (a kernel that runs several times per step, like the pyramid levels, counts with all its launches)
+    data[workload + "_all_kernels"] = tf["sum"] * 1024 * 2 / tf["steps"] + tw["sum"] * 1024 / tw["steps"]
     data[workload + "_detail"] = {"per_kernel_per_launch": detail, "source": tag,
                                   "note": "FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), WRITE_SIZE KiB x 1024"}
     json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)
