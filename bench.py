@@ -553,14 +553,18 @@ def main(argv=None):
         if world > 1:
             dist.barrier()
 
-    def gather_results(Rt, lastc):
+    def gather_results(Rt, lastc, info):
         """the only collective of the weak-scaling workloads: the per-frame relative poses of every rank, and the point clouds
         (triangulated points) of the last batch as fixed-size padded buffers (result gather, RCCL over xGMI)"""
         poses = torch.from_numpy(np.ascontiguousarray(Rt)).to(cdev)
         gathered = [torch.empty_like(poses) for _ in range(world)]
         dist.all_gather(gathered, poses)
         out = {r: g.cpu().numpy() for r, g in enumerate(gathered)}
-        clouds = vseq.gather_point_clouds([lastc.object_points(b)[0] for b in range(B)], cap=shape["max_features"])
+        if stub:
+            mine = [lastc.object_points(b)[0] for b in range(B)]
+        else:   # one strided copy for the whole batch
+            mine = lastc.object_points_batch()
+        clouds = vseq.gather_point_clouds(mine, cap=shape["max_features"])
         assert len(clouds) == world
         dev_sync()
         return out, clouds
@@ -621,7 +625,7 @@ def main(argv=None):
         t_compute = time.perf_counter() - t0
         clouds = None
         if collective:
-            gathered_poses, clouds = gather_results(Rt, ctxs[(args.steps - 1) % nctx])
+            gathered_poses, clouds = gather_results(Rt, ctxs[(args.steps - 1) % nctx], info)
         else:
             gathered_poses = {0: np.asarray(Rt)}
         my_steps = args.steps * B

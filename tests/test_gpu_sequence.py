@@ -43,6 +43,13 @@ def test_sequence_mode_equals_pair_mode(frames5):
         for x, y in zip(ctx.object_points(b), pair[b][4]):
             assert np.array_equal(x, y)
         assert info_a[b].n_matched == info_b[b].n_matched and info_a[b].best_inliers == info_b[b].best_inliers
+    # the whole batch's triangulated points with one copy: the same sets as frame by frame
+    batch = ctx.object_points_batch()
+    assert len(batch) == n
+    for b in range(n):
+        assert np.array_equal(batch[b], ctx.object_points(b)[0])
+    capped = ctx.object_points_batch(cap=10)
+    assert all(len(capped[b]) == min(10, len(batch[b])) and np.array_equal(capped[b], batch[b][:10]) for b in range(n))
     # the pyramid taps address (frame, side) slots in this mode: pair 1's LT1 pyramid is pair 0's LT2 pyramid
     a = ctx.tap(abi.TAP_PYR_LEVEL, 0, 2, 1)   # pair 0, image slot 2 (LT2), level 1
     b_ = ctx.tap(abi.TAP_PYR_LEVEL, 1, 0, 1)  # pair 1, image slot 0 (LT1), level 1

@@ -7,6 +7,7 @@
 //   v2  one row per wavefront, 64 lanes x 16 bytes = 1 KiB contiguous per instruction (a plain stream);
 //   v3  v0 with 16 columns per group;
 //   v4  v1 with the group of 8 columns requested TWO groups ahead;
+//   v5  v0 plus the checkpoint pass's stores (16 bytes per lane every 16 columns), v6 the same with non-temporal stores;
 // each with a trivial consumer (xor).  hipcc --offload-arch=gfx950 -O3 -o row_stream tools/micro/row_stream.hip && ./row_stream
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -17,8 +18,8 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 constexpr int D = 96, COLS = 1145, ROW_BYTES = COLS * D * 2;
 
-template <int U>
-__global__ __launch_bounds__(256) void k_v0(const char* __restrict__ vol, int rows, unsigned* out)
+template <int U, int STORE = 0>
+__global__ __launch_bounds__(256) void k_v0(const char* __restrict__ vol, int rows, unsigned* out, unsigned* ck = nullptr)
 {
     const int lane16 = threadIdx.x & 15, y = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (y >= rows) return;
@@ -31,6 +32,23 @@ __global__ __launch_bounds__(256) void k_v0(const char* __restrict__ vol, int ro
             for (int u = 0; u < U; u++) nxt[u] = *reinterpret_cast<const v3u*>(p + (size_t)min(x0 + U + u, COLS - 1) * 192);
         for (int u = 0; u < U; u++) acc ^= cur[u];
         for (int u = 0; u < U; u++) cur[u] = nxt[u];
+        if (STORE == 3 && (x0 % 16) == 0) { // one contiguous KiB per wavefront and store instruction
+            unsigned* q = ck + (((size_t)(y >> 2) * 72 + x0 / 16) * 64 + (threadIdx.x & 63)) * 4;
+            *reinterpret_cast<v4u*>(q) = v4u{acc.x, acc.y, acc.z, acc.x ^ acc.y};
+        } else if (STORE == 4 && (x0 % 16) == 0) { // 12 bytes per lane
+            unsigned* q = ck + (((size_t)y * 72 + x0 / 16) * 16 + lane16) * 3;
+            *reinterpret_cast<v3u*>(q) = acc;
+        } else if (STORE == 5 && (x0 % 64) == 0) { // four segments' worth at once, every 64 columns
+            unsigned* q = ck + (((size_t)y * 18 + x0 / 64) * 16 + lane16) * 16;
+            for (int i = 0; i < 4; i++) *reinterpret_cast<v4u*>(q + 4 * i) = v4u{acc.x + i, acc.y, acc.z, acc.x ^ acc.y};
+        } else if (STORE == 6 && (x0 % 16) == 0) { // 16 bytes per lane as one dwordx4 (v5 writes four dwords)
+            unsigned* q = ck + (((size_t)y * 72 + x0 / 16) * 16 + lane16) * 4;
+            *reinterpret_cast<v4u*>(q) = v4u{acc.x, acc.y, acc.z, acc.x ^ acc.y};
+        } else if (STORE && STORE <= 2 && (x0 % 16) == 0) { // the checkpoint pass's stores: 16 bytes per lane every 16 columns
+            unsigned* q = ck + (((size_t)y * 72 + x0 / 16) * 16 + lane16) * 4;
+            if (STORE == 2) { __builtin_nontemporal_store(acc.x, q); __builtin_nontemporal_store(acc.y, q + 1); __builtin_nontemporal_store(acc.z, q + 2); __builtin_nontemporal_store(acc.x ^ acc.y, q + 3); }
+            else { q[0] = acc.x; q[1] = acc.y; q[2] = acc.z; q[3] = acc.x ^ acc.y; }
+        }
     }
     if (acc.x == 0x12345 && acc.y == 77) out[threadIdx.x] = acc.z;
 }
@@ -83,8 +101,8 @@ int main()
 {
     const int rows = 42 * 376;
     const size_t bytes = (size_t)rows * ROW_BYTES;
-    char* vol; unsigned* out;
-    if (hipMalloc(&vol, bytes + 4096) != hipSuccess || hipMalloc(&out, 4096) != hipSuccess) return 1;
+    char* vol; unsigned* out; unsigned* ck;
+    if (hipMalloc(&vol, bytes + 4096) != hipSuccess || hipMalloc(&out, 4096) != hipSuccess || hipMalloc(&ck, (size_t)rows * 72 * 16 * 16) != hipSuccess) return 1;
     (void)hipMemset(vol, 1, bytes + 4096);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     auto run = [&](const char* name, auto launch) {
@@ -96,6 +114,12 @@ int main()
         printf("%-64s %7.1f GB/s  %.3f ms\n", name, 5 * (double)bytes / (ms * 1e-3) / 1e9, ms / 5);
     };
     run("v0 4 rows/wave, dwordx3 per column, 8 columns ahead", [&] { hipLaunchKernelGGL(k_v0<8>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out); });
+    run("v5 v0 + the checkpoint stores (16 B per lane every 16 columns)", [&] { hipLaunchKernelGGL((k_v0<8, 1>), dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
+    run("v6 v5 with non-temporal stores", [&] { hipLaunchKernelGGL((k_v0<8, 2>), dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
+    run("v7 v0 + one contiguous KiB per wavefront store", [&] { hipLaunchKernelGGL((k_v0<8, 3>), dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
+    run("v8 v0 + 12 B per lane stores", [&] { hipLaunchKernelGGL((k_v0<8, 4>), dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
+    run("v9 v0 + four segments per store burst (every 64 columns)", [&] { hipLaunchKernelGGL((k_v0<8, 5>), dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
+    run("v10 v0 + 16 B per lane as one dwordx4", [&] { hipLaunchKernelGGL((k_v0<8, 6>), dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
     run("v3 4 rows/wave, dwordx3 per column, 16 columns ahead", [&] { hipLaunchKernelGGL(k_v0<16>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out); });
     run("v1 4 rows/wave, 256 B per row and instruction, 1 group ahead", [&] { hipLaunchKernelGGL(k_v1<1>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out); });
     run("v4 4 rows/wave, 256 B per row and instruction, 2 groups ahead", [&] { hipLaunchKernelGGL(k_v1<2>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out); });

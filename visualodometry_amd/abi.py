@@ -22,7 +22,7 @@ EXPORTS = (
     "vo_set_calib", "vo_set_images", "vo_set_images_device", "vo_set_sequence", "vo_set_sequence_device",
     "vo_compute_disparity", "vo_get_disparity16",
     "vo_get_disparity32", "vo_compute_depth_map", "vo_get_depth", "vo_set_disparity32", "vo_set_depth", "vo_get_depth_cloud", "vo_detect_fast", "vo_get_features", "vo_set_features", "vo_detect_fast_noalloc",
-    "vo_match_klt", "vo_get_matches", "vo_get_klt_legs", "vo_set_matches", "vo_triangulate", "vo_get_object_points",
+    "vo_match_klt", "vo_get_matches", "vo_get_klt_legs", "vo_set_matches", "vo_triangulate", "vo_get_object_points", "vo_get_object_points_batch",
     "vo_pnp_score", "vo_estimate_motion", "vo_integrate_pose", "vo_step", "vo_step_submit", "vo_step_finish", "vo_read_tap", "vo_pyramid_info",
     "vo_set_timing", "vo_get_timing", "vo_stage_name",
     "vo_host_epnp", "vo_host_pnp_iterative", "vo_host_p3p", "vo_host_rng_subsets", "vo_host_rodrigues",
@@ -273,13 +273,29 @@ class Context:
     def triangulate(self):
         self._check(self._L.vo_triangulate(self._h))
 
-    def object_points(self, b=0):
-        k = C.c_int()
-        self._check(self._L.vo_get_object_points(self._h, b, None, None, 0, C.byref(k)))
-        obj = np.empty((max(k.value, 1), 3), dtype=np.float32)
-        img = np.empty((max(k.value, 1), 2), dtype=np.float32)
-        self._check(self._L.vo_get_object_points(self._h, b, _ptr(obj), _ptr(img), k.value, C.byref(k)))
-        return obj[:k.value], img[:k.value]
+    def object_points(self, b=0, k=None, with_image_points=True):
+        """Triangulated points of frame b (and their T2 image points).  k: the count if the caller already knows it (the
+        frame info of a step carries it), which saves the query; with_image_points=False fetches the 3-D points only."""
+        if k is None:
+            kk = C.c_int()
+            self._check(self._L.vo_get_object_points(self._h, b, None, None, 0, C.byref(kk)))
+            k = kk.value
+        kk = C.c_int()
+        obj = np.empty((max(k, 1), 3), dtype=np.float32)
+        img = np.empty((max(k, 1), 2), dtype=np.float32) if with_image_points else None
+        self._check(self._L.vo_get_object_points(self._h, b, _ptr(obj), _ptr(img) if with_image_points else None, k, C.byref(kk)))
+        k = min(k, kk.value)
+        return (obj[:k], img[:k]) if with_image_points else obj[:k]
+
+    def object_points_batch(self, cap=None):
+        """The triangulated points of every frame of the batch with one copy: a list of [k_b, 3] float32 arrays."""
+        n = self.n
+        counts = (C.c_int * n)()
+        self._check(self._L.vo_get_object_points_batch(self._h, None, None, 0, counts))
+        cap = max(1, max(counts) if cap is None else min(cap, max(counts)))
+        obj = np.empty((n, cap, 3), dtype=np.float32)
+        self._check(self._L.vo_get_object_points_batch(self._h, _ptr(obj), None, cap, counts))
+        return [obj[b, :min(counts[b], cap)] for b in range(n)]
 
     def pnp_score(self, Rt12, thresh2=64.0, b=0, with_masks=False, k=None):
         Rt12 = np.ascontiguousarray(Rt12, dtype=np.float64).reshape(-1, 12)

@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void hpath_ckpt_kernel(const int16_t* __restri
     // Columns are consumed in groups of U, and a group is requested TWO groups before it is consumed: the kernel runs at
     // memory speed, where a request takes several microseconds to come back, longer than one group's arithmetic.  Three
     // register groups take turns (the loop body is written out three times so that no group is ever copied).
-    constexpr int U = NP >= 5 ? 4 : 8; // 3 U NP registers hold the groups
+    constexpr int U = 4; // 3 U NP registers hold the groups (8 columns per group are no faster)
     v2s g0[U][NP], g1[U][NP], g2[U][NP];
     auto load_group = [&](int x0, v2s (&g)[U][NP]) {
         if (x0 >= width1) return; // uniform
@@ -579,9 +579,16 @@ __global__ __launch_bounds__(256) void hpath_ckpt_kernel(const int16_t* __restri
             for (int k = 0; k < NP; k++) q[k] = as_int(Lp[k]);
             q[NP] = m;
         }
+        if (x0 + U <= width1) {
+            // a whole group as one straight run of instructions: the scheduler can start a column's neighbour terms while the
+            // previous column's row minimum is still going through its DPP steps
 #pragma unroll
-        for (int u = 0; u < U; u++)
-            if (x0 + u < width1) m = path_step<NP>(g[u], Lp, m, P1, P2, inf_pk);
+            for (int u = 0; u < U; u++) m = path_step<NP>(g[u], Lp, m, P1, P2, inf_pk);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (x0 + u < width1) m = path_step<NP>(g[u], Lp, m, P1, P2, inf_pk);
+        }
     };
     load_group(0, g0);
     load_group(U, g1);

@@ -115,26 +115,30 @@ def gather_trajectories(local, n_sequences, max_steps, group=None):
 
 def gather_point_clouds(clouds, cap, group=None):
     """clouds: this rank's list of [k_i, 3] float32 point sets (the triangulated points of its frame pairs, k_i <= cap), the
-    same number of sets on every rank.  One all_gather of fixed-size padded buffers (plus one of the counts); returns, on
-    every rank, a list over ranks of lists of [k_i, 3] arrays."""
+    same number of sets on every rank.  One all_gather of the counts, then one of fixed-size buffers padded to the largest
+    count of any rank (not to `cap`: a KITTI-shape frame has about 4 000 points for a capacity of 16 384); returns, on every
+    rank, a list over ranks of lists of [k_i, 3] arrays."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
     n = len(clouds)
-    buf = torch.zeros((n, cap, 3), dtype=torch.float32)
-    cnt = torch.zeros((n,), dtype=torch.int64)
-    for i, pts in enumerate(clouds):
-        a = np.asarray(pts, dtype=np.float32).reshape(-1, 3)
+    arrs = [np.asarray(pts, dtype=np.float32).reshape(-1, 3) for pts in clouds]
+    for i, a in enumerate(arrs):
         if a.shape[0] > cap:
             raise ValueError("point set %d has %d points, capacity %d" % (i, a.shape[0], cap))
-        buf[i, :a.shape[0]] = torch.from_numpy(a)
-        cnt[i] = a.shape[0]
     if not dist.is_initialized():
-        return [[buf[i, :int(cnt[i])].numpy().copy() for i in range(n)]]
+        return [[a.copy() for a in arrs]]
+    world = dist.get_world_size(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    buf, cnt = buf.to(dev), cnt.to(dev)
-    bufs = [torch.empty_like(buf) for _ in range(world)]
+    cnt = torch.tensor([a.shape[0] for a in arrs], dtype=torch.int64).to(dev)
     cnts = [torch.empty_like(cnt) for _ in range(world)]
-    dist.all_gather(bufs, buf, group=group)
     dist.all_gather(cnts, cnt, group=group)
-    return [[bufs[r][i, :int(cnts[r][i])].cpu().numpy().copy() for i in range(n)] for r in range(world)]
+    cnts = [c.cpu() for c in cnts]
+    kmax = max(1, max(int(c.max()) if c.numel() else 0 for c in cnts))
+    buf = torch.zeros((n, kmax, 3), dtype=torch.float32)
+    for i, a in enumerate(arrs):
+        buf[i, :a.shape[0]] = torch.from_numpy(a)
+    buf = buf.to(dev)
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    bufs = [x.cpu().numpy() for x in bufs]
+    return [[bufs[r][i, :int(cnts[r][i])].copy() for i in range(n)] for r in range(world)]
