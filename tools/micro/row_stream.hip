@@ -44,11 +44,40 @@ __global__ __launch_bounds__(256) void k_v0(const char* __restrict__ vol, int ro
         } else if (STORE == 6 && (x0 % 16) == 0) { // 16 bytes per lane as one dwordx4 (v5 writes four dwords)
             unsigned* q = ck + (((size_t)y * 72 + x0 / 16) * 16 + lane16) * 4;
             *reinterpret_cast<v4u*>(q) = v4u{acc.x, acc.y, acc.z, acc.x ^ acc.y};
+        } else if (STORE == 7 && (x0 % 64) == 0) { // a quarter of the stores: 16 bytes per lane every 64 columns
+            unsigned* q = ck + (((size_t)y * 18 + x0 / 64) * 16 + lane16) * 4;
+            *reinterpret_cast<v4u*>(q) = v4u{acc.x, acc.y, acc.z, acc.x ^ acc.y};
+        } else if (STORE == 8 && (x0 % 16) == 0) { // the same stores into a region small enough to stay in the L2 caches (1 MiB)
+            unsigned* q = ck + ((((size_t)y * 72 + x0 / 16) * 16 + lane16) * 4) % (1u << 18);
+            *reinterpret_cast<v4u*>(q) = v4u{acc.x, acc.y, acc.z, acc.x ^ acc.y};
+        } else if (STORE == 9 && (x0 % 16) == 0) { // 4 bytes per lane (the resolve pass's packed winners)
+            unsigned* q = ck + ((size_t)y * 72 + x0 / 16) * 16 + lane16;
+            *q = acc.x;
         } else if (STORE && STORE <= 2 && (x0 % 16) == 0) { // the checkpoint pass's stores: 16 bytes per lane every 16 columns
             unsigned* q = ck + (((size_t)y * 72 + x0 / 16) * 16 + lane16) * 4;
             if (STORE == 2) { __builtin_nontemporal_store(acc.x, q); __builtin_nontemporal_store(acc.y, q + 1); __builtin_nontemporal_store(acc.z, q + 2); __builtin_nontemporal_store(acc.x ^ acc.y, q + 3); }
             else { q[0] = acc.x; q[1] = acc.y; q[2] = acc.z; q[3] = acc.x ^ acc.y; }
         }
+    }
+    if (acc.x == 0x12345 && acc.y == 77) out[threadIdx.x] = acc.z;
+}
+
+// v0 + the checkpoint stores with nothing conditional in the loop: requests clamped to the last column, a store every 16 columns
+__global__ __launch_bounds__(256) void k_v14(const char* __restrict__ vol, int rows, unsigned* out, unsigned* ck)
+{
+    constexpr int U = 8;
+    const int lane16 = threadIdx.x & 15, y = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (y >= rows) return;
+    const char* p = vol + (size_t)y * ROW_BYTES + lane16 * 12;
+    v3u a[U], b[U], acc = {0, 0, 0};
+    for (int u = 0; u < U; u++) a[u] = *reinterpret_cast<const v3u*>(p + (size_t)u * 192);
+    for (int x0 = 0; x0 < COLS; x0 += 2 * U) {
+        for (int u = 0; u < U; u++) b[u] = *reinterpret_cast<const v3u*>(p + (size_t)min(x0 + U + u, COLS - 1) * 192);
+        unsigned* q = ck + (((size_t)y * 72 + x0 / 16) * 16 + lane16) * 4;
+        *reinterpret_cast<v4u*>(q) = v4u{acc.x, acc.y, acc.z, acc.x ^ acc.y};
+        for (int u = 0; u < U; u++) acc ^= a[u];
+        for (int u = 0; u < U; u++) a[u] = *reinterpret_cast<const v3u*>(p + (size_t)min(x0 + 2 * U + u, COLS - 1) * 192);
+        for (int u = 0; u < U; u++) acc ^= b[u];
     }
     if (acc.x == 0x12345 && acc.y == 77) out[threadIdx.x] = acc.z;
 }
@@ -120,6 +149,10 @@ int main()
     run("v8 v0 + 12 B per lane stores", [&] { hipLaunchKernelGGL((k_v0<8, 4>), dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
     run("v9 v0 + four segments per store burst (every 64 columns)", [&] { hipLaunchKernelGGL((k_v0<8, 5>), dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
     run("v10 v0 + 16 B per lane as one dwordx4", [&] { hipLaunchKernelGGL((k_v0<8, 6>), dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
+    run("v11 v0 + a quarter of the stores (16 B per lane every 64 columns)", [&] { hipLaunchKernelGGL((k_v0<8, 7>), dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
+    run("v12 v0 + the stores into 1 MiB that stays in cache", [&] { hipLaunchKernelGGL((k_v0<8, 8>), dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
+    run("v13 v0 + 4 B per lane every 16 columns", [&] { hipLaunchKernelGGL((k_v0<8, 9>), dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
+    run("v14 v10 with nothing conditional in the loop", [&] { hipLaunchKernelGGL(k_v14, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
     run("v3 4 rows/wave, dwordx3 per column, 16 columns ahead", [&] { hipLaunchKernelGGL(k_v0<16>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out); });
     run("v1 4 rows/wave, 256 B per row and instruction, 1 group ahead", [&] { hipLaunchKernelGGL(k_v1<1>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out); });
     run("v4 4 rows/wave, 256 B per row and instruction, 2 groups ahead", [&] { hipLaunchKernelGGL(k_v1<2>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out); });

@@ -186,22 +186,39 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 #define VO_BUF_SKIP 0x80000000u // lane offset of a store that must not happen: past any buffer this file describes
 // NP packed pairs to byte offset `off` of the buffer, streamed (non-temporal: read back by later kernels only, and must
 // not displace the ring and the image rows in cache)
-template <int NP, int K = 0>
-__device__ __forceinline__ void store_pk_buf(__amdgpu_buffer_rsrc_t rs, unsigned off, const v2s (&v)[NP])
+template <int NP, int K = 0, int NT = 2>
+__device__ __forceinline__ void store_pk_buf(__amdgpu_buffer_rsrc_t rs, unsigned off, const v2s (&v)[NP], int soff = 0)
 {
-    constexpr int NT = 2;
     if constexpr (NP - K >= 4) {
         v4u32 t = {(unsigned)as_int(v[K]), (unsigned)as_int(v[K + 1]), (unsigned)as_int(v[K + 2]), (unsigned)as_int(v[K + 3])};
-        __builtin_amdgcn_raw_buffer_store_b128(t, rs, (int)off + 4 * K, 0, NT);
-        store_pk_buf<NP, K + 4>(rs, off, v);
+        __builtin_amdgcn_raw_buffer_store_b128(t, rs, (int)off + 4 * K, soff, NT);
+        store_pk_buf<NP, K + 4, NT>(rs, off, v, soff);
     } else if constexpr (NP - K == 3) {
         v3u32 t = {(unsigned)as_int(v[K]), (unsigned)as_int(v[K + 1]), (unsigned)as_int(v[K + 2])};
-        __builtin_amdgcn_raw_buffer_store_b96(t, rs, (int)off + 4 * K, 0, NT);
+        __builtin_amdgcn_raw_buffer_store_b96(t, rs, (int)off + 4 * K, soff, NT);
     } else if constexpr (NP - K == 2) {
         v2u32 t = {(unsigned)as_int(v[K]), (unsigned)as_int(v[K + 1])};
-        __builtin_amdgcn_raw_buffer_store_b64(t, rs, (int)off + 4 * K, 0, NT);
+        __builtin_amdgcn_raw_buffer_store_b64(t, rs, (int)off + 4 * K, soff, NT);
     } else if constexpr (NP - K == 1) {
-        __builtin_amdgcn_raw_buffer_store_b32((unsigned)as_int(v[K]), rs, (int)off + 4 * K, 0, NT);
+        __builtin_amdgcn_raw_buffer_store_b32((unsigned)as_int(v[K]), rs, (int)off + 4 * K, soff, NT);
+    }
+}
+// NP packed pairs from lane offset `off` + uniform offset `soff` of the buffer: no address arithmetic in vector registers
+template <int NP, int K = 0>
+__device__ __forceinline__ void load_pk_buf(__amdgpu_buffer_rsrc_t rs, unsigned off, int soff, v2s (&v)[NP])
+{
+    if constexpr (NP - K >= 4) {
+        const v4u32 t = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off + 4 * K, soff, 0);
+        v[K] = as_v2s((int)t.x); v[K + 1] = as_v2s((int)t.y); v[K + 2] = as_v2s((int)t.z); v[K + 3] = as_v2s((int)t.w);
+        load_pk_buf<NP, K + 4>(rs, off, soff, v);
+    } else if constexpr (NP - K == 3) {
+        const v3u32 t = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)off + 4 * K, soff, 0);
+        v[K] = as_v2s((int)t.x); v[K + 1] = as_v2s((int)t.y); v[K + 2] = as_v2s((int)t.z);
+    } else if constexpr (NP - K == 2) {
+        const v2u32 t = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off + 4 * K, soff, 0);
+        v[K] = as_v2s((int)t.x); v[K + 1] = as_v2s((int)t.y);
+    } else if constexpr (NP - K == 1) {
+        v[K] = as_v2s((int)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)off + 4 * K, soff, 0));
     }
 }
 
@@ -543,6 +560,8 @@ __device__ __forceinline__ int stripe_row_of(const StripeInfo& si, int stripe_sz
     return si.off[s] + (y - si.y0[s]);
 }
 
+constexpr int vo_gcd(int a, int b) { return b == 0 ? a : vo_gcd(b, a % b); }
+
 template <int NP>
 __global__ __launch_bounds__(256) void hpath_ckpt_kernel(const int16_t* __restrict__ cost, int width1, int D, int H, int srows, StripeInfo si,
                                                          int stripe_sz, int P1, int P2, int nseg, int* __restrict__ ckpt)
@@ -551,11 +570,19 @@ __global__ __launch_bounds__(256) void hpath_ckpt_kernel(const int16_t* __restri
     const int lane16 = threadIdx.x & 15;
     const int y = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int b = blockIdx.y;
-    const bool active = y < H;
-    const int yy = active ? y : H - 1;
+    // rows past the image repeat the last row: they compute and store exactly what its own lanes do
+    const int yy = min(y, H - 1);
     const int sr = stripe_row_of(si, stripe_sz, yy);
-    const int16_t* Cp = cost + (((size_t)b * srows + sr) * width1) * D + lane16 * (2 * NP);
-    int* ck = ckpt + (((size_t)b * H + yy) * nseg * 16 + lane16) * (NP + 1);
+    // One descriptor per wavefront at its first row; a lane's offset is its row's distance from there (four consecutive image
+    // rows, at most a stripe's warm-up rows apart in the volume) plus its disparities, the column is a uniform scalar offset:
+    // a column's address costs no vector instruction and no vector register.
+    const int sr0 = __builtin_amdgcn_readfirstlane(sr), yy0 = __builtin_amdgcn_readfirstlane(yy);
+    const unsigned col_bytes = (unsigned)D * 2u, row_bytes = (unsigned)width1 * col_bytes;
+    const __amdgpu_buffer_rsrc_t Crs = make_rsrc(cost + ((size_t)b * srows + sr0) * width1 * D, 0x7fffffffu);
+    const unsigned coff = (unsigned)(sr - sr0) * row_bytes + (unsigned)lane16 * (4u * NP);
+    const unsigned seg_bytes = 16u * (NP + 1) * 4u;
+    const __amdgpu_buffer_rsrc_t Krs = make_rsrc(ckpt + ((size_t)b * H + yy0) * nseg * 16 * (NP + 1), 0x7fffffffu);
+    const unsigned koff = (unsigned)(yy - yy0) * (unsigned)nseg * seg_bytes + (unsigned)lane16 * (4u * (NP + 1));
     const int inf_pk = (32767 - P1) * 0x10001;
     v2s Lp[NP];
 #pragma unroll
@@ -563,39 +590,48 @@ __global__ __launch_bounds__(256) void hpath_ckpt_kernel(const int16_t* __restri
     int m = 0;
     // Columns are consumed in groups of U, and a group is requested TWO groups before it is consumed: the kernel runs at
     // memory speed, where a request takes several microseconds to come back, longer than one group's arithmetic.  Three
-    // register groups take turns (the loop body is written out three times so that no group is ever copied).
-    constexpr int U = 4; // 3 U NP registers hold the groups (8 columns per group are no faster)
-    v2s g0[U][NP], g1[U][NP], g2[U][NP];
-    auto load_group = [&](int x0, v2s (&g)[U][NP]) {
-        if (x0 >= width1) return; // uniform
+    // register groups take turns.  The body is written out for a whole PERIOD of columns (the checkpoint spacing and the
+    // rotation of the groups repeat after it) as ONE straight run, requests clamped to the last column instead of skipped
+    // and checkpoints at fixed places: behind a branch the compiler must assume the worst about the requests in flight and
+    // waits for all of them, which leaves one group in flight instead of two.
+    constexpr int U = 4, PERIOD = HP_SEG * (3 * U) / vo_gcd(HP_SEG, 3 * U), NG = PERIOD / U;
+    static_assert(NG % 3 == 0 && HP_SEG % U == 0, "group rotation and checkpoint spacing must divide the period");
+    v2s g[3][U][NP];
+    auto load_group = [&](int x0, v2s (&gr)[U][NP]) {
 #pragma unroll
-        for (int u = 0; u < U; u++) load_pk<NP>(Cp + (size_t)min(x0 + u, width1 - 1) * D, g[u]);
+        for (int u = 0; u < U; u++) load_pk_buf<NP>(Crs, coff, min(x0 + u, width1 - 1) * (int)col_bytes, gr[u]);
     };
-    auto process = [&](int x0, v2s (&g)[U][NP]) {
-        if (x0 >= width1) return; // uniform
-        if ((x0 % HP_SEG) == 0 && active) { // state before column x0
-            int* q = ck + (size_t)(x0 / HP_SEG) * 16 * (NP + 1);
+    auto checkpoint = [&](int x0) { // state before column x0
+        v2s t[NP + 1];
 #pragma unroll
-            for (int k = 0; k < NP; k++) q[k] = as_int(Lp[k]);
-            q[NP] = m;
-        }
-        if (x0 + U <= width1) {
-            // a whole group as one straight run of instructions: the scheduler can start a column's neighbour terms while the
-            // previous column's row minimum is still going through its DPP steps
-#pragma unroll
-            for (int u = 0; u < U; u++) m = path_step<NP>(g[u], Lp, m, P1, P2, inf_pk);
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (x0 + u < width1) m = path_step<NP>(g[u], Lp, m, P1, P2, inf_pk);
-        }
+        for (int k = 0; k < NP; k++) t[k] = Lp[k];
+        t[NP] = as_v2s(m);
+        store_pk_buf<NP + 1, 0, 0>(Krs, koff, t, (x0 / HP_SEG) * (int)seg_bytes);
     };
-    load_group(0, g0);
-    load_group(U, g1);
-    for (int x0 = 0; x0 < width1; x0 += 3 * U) {
-        load_group(x0 + 2 * U, g2); process(x0, g0);
-        load_group(x0 + 3 * U, g0); process(x0 + U, g1);
-        load_group(x0 + 4 * U, g1); process(x0 + 2 * U, g2);
+    load_group(0, g[0]);
+    load_group(U, g[1]);
+    int xb = 0;
+    for (; xb + PERIOD <= width1; xb += PERIOD) {
+#pragma unroll
+        for (int i = 0; i < NG; i++) {
+            load_group(xb + (i + 2) * U, g[(i + 2) % 3]);
+            if ((i * U) % HP_SEG == 0) checkpoint(xb + i * U);
+            __builtin_amdgcn_sched_barrier(0); // the requests stay here, two groups ahead of their use
+#pragma unroll
+            for (int u = 0; u < U; u++) m = path_step<NP>(g[i % 3][u], Lp, m, P1, P2, inf_pk);
+        }
+    }
+    // the rest of the row (less than a period): the same groups, each behind its own test
+#pragma unroll
+    for (int i = 0; i < NG; i++) {
+        const int x0 = xb + i * U;
+        if (x0 >= width1) break; // uniform
+        load_group(x0 + 2 * U, g[(i + 2) % 3]);
+        if ((i * U) % HP_SEG == 0) checkpoint(x0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (x0 + u < width1) m = path_step<NP>(g[i % 3][u], Lp, m, P1, P2, inf_pk);
     }
 }
 
@@ -613,10 +649,16 @@ __global__ __launch_bounds__(64, (NP >= 7 ? 2 : 1)) void hpath_resolve_kernel(co
     const bool active = y < H;
     const int yy = active ? y : H - 1;
     const int sr = stripe_row_of(si, stripe_sz, yy);
-    const size_t base = (((size_t)b * srows + sr) * width1) * Dp + lane16 * (2 * NP);
-    const int16_t* Cp = cost + base;
-    const int16_t* Tp = ltop + base;
-    const int* ck = ckpt + (((size_t)b * H + yy) * nseg * 16 + lane16) * (NP + 1);
+    // One descriptor per volume at the wavefront's first row; a lane's offset is its row's distance from there plus its
+    // disparities, the column is a uniform scalar offset: a column's address costs no vector instruction or register.
+    const int sr0 = __builtin_amdgcn_readfirstlane(sr), yy0 = __builtin_amdgcn_readfirstlane(yy);
+    const unsigned col_bytes = (unsigned)Dp * 2u, row_bytes = (unsigned)width1 * col_bytes;
+    const size_t base0 = (((size_t)b * srows + sr0) * width1) * Dp;
+    const __amdgpu_buffer_rsrc_t Crs = make_rsrc(cost + base0, 0x7fffffffu), Trs = make_rsrc(ltop + base0, 0x7fffffffu);
+    const unsigned voff = (unsigned)(sr - sr0) * row_bytes + (unsigned)lane16 * (4u * NP);
+    const unsigned seg_bytes = 16u * (NP + 1) * 4u;
+    const __amdgpu_buffer_rsrc_t Krs = make_rsrc(ckpt + ((size_t)b * H + yy0) * nseg * 16 * (NP + 1), 0x7fffffffu);
+    const unsigned koff = (unsigned)(yy - yy0) * (unsigned)nseg * seg_bytes + (unsigned)lane16 * (4u * (NP + 1));
     int32_t* out = wta + ((size_t)b * srows + sr) * W + (W - width1);
     const int inf_pk = (32767 - P1) * 0x10001;
     // exchange buffer of this row (16 lanes): [column of the segment][D / 2 packed sums], odd stride against bank conflicts
@@ -631,26 +673,30 @@ __global__ __launch_bounds__(64, (NP >= 7 ? 2 : 1)) void hpath_resolve_kernel(co
 
     v2s Cc[HP_SEG][NP], Cn[HP_SEG][NP], Tt[HP_SEG][NP], Lrec[HP_SEG][NP];
     int ckc[NP + 1], ckn[NP + 1];
-    auto load_cols = [&](const int16_t* p, int s, v2s (&g)[HP_SEG][NP], int u0, int u1) {
+    auto load_cols = [&](const __amdgpu_buffer_rsrc_t& rs, int s, v2s (&g)[HP_SEG][NP], int u0, int u1) {
 #pragma unroll
         for (int u = 0; u < HP_SEG; u++)
-            if (u >= u0 && u < u1) load_pk<NP>(p + (size_t)min(s * HP_SEG + u, width1 - 1) * Dp, g[u]);
+            if (u >= u0 && u < u1) load_pk_buf<NP>(rs, voff, min(s * HP_SEG + u, width1 - 1) * (int)col_bytes, g[u]);
     };
-    auto load_seg = [&](const int16_t* p, int s, v2s (&g)[HP_SEG][NP]) { load_cols(p, s, g, 0, HP_SEG); };
+    auto load_seg = [&](const __amdgpu_buffer_rsrc_t& rs, int s, v2s (&g)[HP_SEG][NP]) { load_cols(rs, s, g, 0, HP_SEG); };
     auto load_ck = [&](int s, int (&c)[NP + 1]) {
-        const int* q = ck + (size_t)s * 16 * (NP + 1);
+        v2s t[NP + 1];
+        load_pk_buf<NP + 1>(Krs, koff, s * (int)seg_bytes, t);
 #pragma unroll
-        for (int k = 0; k <= NP; k++) c[k] = q[k];
+        for (int k = 0; k <= NP; k++) c[k] = as_int(t[k]);
     };
     // (the widest ranges have no register to spare for a request that overlaps the winner search: they ask at the top of a segment)
     constexpr bool T_EARLY = NP <= 6;
-    load_seg(Cp, nseg - 1, Cc);
+    load_seg(Crs, nseg - 1, Cc);
     load_ck(nseg - 1, ckc);
-    if (T_EARLY) load_seg(Tp, nseg - 1, Tt);
-    for (int s = nseg - 1; s >= 0; s--) {
+    if (T_EARLY) load_seg(Trs, nseg - 1, Tt);
+    // Only the last segment of a row can be short: every other one runs with its column count known at compile time, as one
+    // straight run of instructions without a test per column.
+    auto segment = [&](int s, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
         const int x0 = s * HP_SEG;
-        const int cols = min(HP_SEG, width1 - x0);
-        if (!T_EARLY) load_seg(Tp, s, Tt);
+        const int cols = FULL ? HP_SEG : min(HP_SEG, width1 - x0);
+        if (!T_EARLY) load_seg(Trs, s, Tt);
         // replay L_lr over the segment
         v2s Lp[NP];
 #pragma unroll
@@ -660,15 +706,15 @@ __global__ __launch_bounds__(64, (NP >= 7 ? 2 : 1)) void hpath_resolve_kernel(co
         for (int u = 0; u < HP_SEG; u++) {
 #pragma unroll
             for (int k = 0; k < NP; k++) Lrec[u][k] = u == 0 ? Lp[k] : Lrec[u - 1][k];
-            if (u < cols) m = path_step<NP>(Cc[u], Lrec[u], m, P1, P2, inf_pk); // steps in place on the column's own registers
+            if (FULL || u < cols) m = path_step<NP>(Cc[u], Lrec[u], m, P1, P2, inf_pk); // steps in place on the column's own registers
         }
         // next segment's C: the half the replay needs first now, the rest once this segment's columns have been consumed
-        if (s > 0) { load_cols(Cp, s - 1, Cn, 0, HP_SEG / 2); load_ck(s - 1, ckn); }
+        if (s > 0) { load_cols(Crs, s - 1, Cn, 0, HP_SEG / 2); load_ck(s - 1, ckn); }
         // L_rl and S, right to left.  S of the segment then goes through LDS so that lane u of the row owns all D sums of
         // column u: the winner search runs once per column on one lane instead of 16 lanes co-operating on every column.
 #pragma unroll
         for (int u = HP_SEG - 1; u >= 0; u--) {
-            if (u < cols) { // uniform
+            if (FULL || u < cols) { // uniform
                 mR = path_step<NP>(Cc[u], LpR, mR, P1, P2, inf_pk);
 #pragma unroll
                 for (int k = 0; k < NP; k++) {
@@ -680,9 +726,9 @@ __global__ __launch_bounds__(64, (NP >= 7 ? 2 : 1)) void hpath_resolve_kernel(co
             // column u of L_top has had its last use: its registers take the same column of the NEXT segment now, so that the
             // request has the rest of this loop, the winner search and the next replay to come back (a request made at the top
             // of the next segment had the replay alone, which is shorter than a trip to memory at full bandwidth)
-            if (T_EARLY && s > 0) load_cols(Tp, s - 1, Tt, u, u + 1);
+            if (T_EARLY && s > 0) load_cols(Trs, s - 1, Tt, u, u + 1);
         }
-        if (s > 0) load_cols(Cp, s - 1, Cn, HP_SEG / 2, HP_SEG);
+        if (s > 0) load_cols(Crs, s - 1, Cn, HP_SEG / 2, HP_SEG);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // same-wavefront exchange: program order in the LDS queue is enough
         {
             const int* col = trow + min(lane16, HP_SEG - 1) * STR;
@@ -727,7 +773,9 @@ __global__ __launch_bounds__(64, (NP >= 7 ? 2 : 1)) void hpath_resolve_kernel(co
             for (int k = 0; k < NP; k++) Cc[u][k] = Cn[u][k];
 #pragma unroll
         for (int k = 0; k <= NP; k++) ckc[k] = ckn[k];
-    }
+    };
+    segment(nseg - 1, std::false_type());
+    for (int s = nseg - 2; s >= 0; s--) segment(s, std::true_type());
 }
 
 // ---------------------------------------------------------------- right-view disparity + consistency check + 3x3 median
