@@ -557,15 +557,25 @@ def main(argv=None):
     def gather_results(Rt, lastc, info):
         """the only collective of the weak-scaling workloads: the per-frame relative poses of every rank, and the point clouds
         (triangulated points) of the last batch as fixed-size padded buffers (result gather, RCCL over xGMI)"""
+        tg = [time.perf_counter()]
         poses = torch.from_numpy(np.ascontiguousarray(Rt)).to(cdev)
         gathered = [torch.empty_like(poses) for _ in range(world)]
         dist.all_gather(gathered, poses)
         out = {r: g.cpu().numpy() for r, g in enumerate(gathered)}
+        tg.append(time.perf_counter())
         if stub:
             mine = [lastc.object_points(b)[0] for b in range(B)]
-        else:   # one strided copy for the whole batch
-            mine = lastc.object_points_batch()
+        else:   # one strided device-to-device copy for the whole batch into the tensor the gather sends
+            counts = lastc.object_points_batch_counts()
+            kloc = max(1, max(counts))
+            pts = torch.empty((B, kloc, 3), dtype=torch.float32, device=dev)
+            lastc.object_points_batch_into(pts.data_ptr(), kloc)
+            mine = (pts if cdev.type == "cuda" else pts.cpu(), counts)
+        tg.append(time.perf_counter())
         clouds = vseq.gather_point_clouds(mine, cap=shape["max_features"])
+        tg.append(time.perf_counter())
+        if os.environ.get("VO_BENCH_GATHER_TIMES"):
+            print("gather ms: poses %.2f, points off the GPU %.2f, clouds %.2f" % tuple(1e3 * (b - a) for a, b in zip(tg, tg[1:])), file=sys.stderr)
         assert len(clouds) == world
         dev_sync()
         return out, clouds
@@ -591,7 +601,7 @@ def main(argv=None):
             else:
                 z = torch.zeros((B, 4, 4), dtype=torch.float64, device=cdev)
                 dist.all_gather([torch.empty_like(z) for _ in range(world)], z)
-                vseq.gather_point_clouds([np.zeros((0, 3), dtype=np.float32)] * B, cap=shape["max_features"])
+                vseq.gather_point_clouds([np.zeros((0, 3), dtype=np.float32)] * B, cap=shape["max_features"], reserve=shape["max_features"])
             z1 = torch.zeros(1, dtype=torch.float64, device=cdev)
             dist.all_reduce(z1, op=dist.ReduceOp.MAX)
             dist.all_gather([torch.empty_like(z1) for _ in range(world)], z1)

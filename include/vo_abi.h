@@ -191,7 +191,9 @@ int vo_set_matches(vo_ctx* ctx, int b, const vo_point2f* t1, const vo_point2f* t
 int vo_triangulate(vo_ctx* ctx);
 int vo_get_object_points(vo_ctx* ctx, int b, vo_point3f* obj, vo_point2f* img2, int cap, int* k_out);
 /* The same for the whole batch with one strided copy per array: frame b's points go to obj[b * cap ..] (img2 likewise; each
- * nullable), at most cap per frame; counts (n ints, nullable) receives every frame's full count.  This is the point-cloud
+ * nullable), at most cap per frame; counts (n ints, nullable) receives every frame's full count.  obj and img2 may point to
+ * host memory or to memory of the context's GPU (a result gather over RCCL takes them without a trip to the host); with both
+ * NULL the call copies nothing and does not synchronise.  This is the point-cloud
  * output that a sequence-sharded run gathers at its end (objectPoints of Source/VOClass.cpp:409-436, one set per frame pair). */
 int vo_get_object_points_batch(vo_ctx* ctx, vo_point3f* obj, vo_point2f* img2, int cap, int* counts);
 

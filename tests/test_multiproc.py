@@ -67,6 +67,16 @@ def cloud_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     got = sequence.gather_point_clouds([cloud_of(rank, i) for i in range(3)], cap=16)
     ok = all(np.array_equal(got[r][i], cloud_of(r, i)) for r in range(world) for i in range(3))
+    # the same sets handed over already padded into one tensor (what a rank does whose points sit in GPU memory); the ranks'
+    # paddings differ, so one of them has to widen its buffer to the other's
+    import torch
+    mine = [cloud_of(rank, i) for i in range(3)]
+    k = max(a.shape[0] for a in mine) + 2 * rank
+    buf = torch.full((3, k, 3), -7.0)
+    for i, a in enumerate(mine):
+        buf[i, :a.shape[0]] = torch.from_numpy(a)
+    got = sequence.gather_point_clouds((buf, [a.shape[0] for a in mine]), cap=16, reserve=16)
+    ok = ok and all(np.array_equal(got[r][i], cloud_of(r, i)) for r in range(world) for i in range(3))
     q.put((rank, ok, len(got)))
     dist.barrier()
     dist.destroy_process_group()

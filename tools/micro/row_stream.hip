@@ -82,6 +82,30 @@ __global__ __launch_bounds__(256) void k_v14(const char* __restrict__ vol, int r
     if (acc.x == 0x12345 && acc.y == 77) out[threadIdx.x] = acc.z;
 }
 
+// v14 with every segment's checkpoint slot inside the volume row, right behind the segment's 16 columns (the stores then go to the
+// memory pages the loads have just opened): a row is 72 x (16 x 192 + 256) bytes
+template <bool INROW>
+__global__ __launch_bounds__(256) void k_v15(char* __restrict__ vol, int rows, unsigned* out, unsigned* ck)
+{
+    constexpr int U = 8, SEGB = 16 * 192 + 256, ROWB = 72 * SEGB;
+    const int lane16 = threadIdx.x & 15, y = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (y >= rows) return;
+    char* p = vol + (size_t)y * ROWB + lane16 * 12;
+    auto at = [&](int x) { x = min(x, COLS - 1); return p + (size_t)(x >> 4) * SEGB + (x & 15) * 192; };
+    v3u a[U], b[U], acc = {0, 0, 0};
+    for (int u = 0; u < U; u++) a[u] = *reinterpret_cast<const v3u*>(at(u));
+    for (int x0 = 0; x0 < COLS; x0 += 2 * U) {
+        for (int u = 0; u < U; u++) b[u] = *reinterpret_cast<const v3u*>(at(x0 + U + u));
+        unsigned* q = INROW ? reinterpret_cast<unsigned*>(vol + (size_t)y * ROWB + (size_t)(x0 >> 4) * SEGB + 16 * 192 + lane16 * 16)
+                            : ck + (((size_t)y * 72 + x0 / 16) * 16 + lane16) * 4;
+        *reinterpret_cast<v4u*>(q) = v4u{acc.x, acc.y, acc.z, acc.x ^ acc.y};
+        for (int u = 0; u < U; u++) acc ^= a[u];
+        for (int u = 0; u < U; u++) a[u] = *reinterpret_cast<const v3u*>(at(x0 + 2 * U + u));
+        for (int u = 0; u < U; u++) acc ^= b[u];
+    }
+    if (acc.x == 0x12345 && acc.y == 77) out[threadIdx.x] = acc.z;
+}
+
 // 16 lanes x 16 bytes per row and instruction; a row is ROW_BYTES = 859 x 256 - 64 bytes: the last piece is clamped
 template <int AHEAD>
 __global__ __launch_bounds__(256) void k_v1(const char* __restrict__ vol, int rows, unsigned* out)
@@ -153,6 +177,14 @@ int main()
     run("v12 v0 + the stores into 1 MiB that stays in cache", [&] { hipLaunchKernelGGL((k_v0<8, 8>), dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
     run("v13 v0 + 4 B per lane every 16 columns", [&] { hipLaunchKernelGGL((k_v0<8, 9>), dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
     run("v14 v10 with nothing conditional in the loop", [&] { hipLaunchKernelGGL(k_v14, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out, ck); });
+    {
+        char* vol2;
+        if (hipMalloc(&vol2, (size_t)rows * 72 * (16 * 192 + 256) + 4096) != hipSuccess) return 1;
+        (void)hipMemset(vol2, 1, (size_t)rows * 72 * (16 * 192 + 256));
+        run("v15 v14 on a volume with a checkpoint slot behind every 16 columns, stores elsewhere", [&] { hipLaunchKernelGGL(k_v15<false>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol2, rows, out, ck); });
+        run("v16 the same, stores into the slots inside the row", [&] { hipLaunchKernelGGL(k_v15<true>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol2, rows, out, ck); });
+        (void)hipFree(vol2);
+    }
     run("v3 4 rows/wave, dwordx3 per column, 16 columns ahead", [&] { hipLaunchKernelGGL(k_v0<16>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out); });
     run("v1 4 rows/wave, 256 B per row and instruction, 1 group ahead", [&] { hipLaunchKernelGGL(k_v1<1>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out); });
     run("v4 4 rows/wave, 256 B per row and instruction, 2 groups ahead", [&] { hipLaunchKernelGGL(k_v1<2>, dim3((rows + 15) / 16), dim3(256), 0, 0, vol, rows, out); });

@@ -297,6 +297,19 @@ class Context:
         self._check(self._L.vo_get_object_points_batch(self._h, _ptr(obj), None, cap, counts))
         return [obj[b, :min(counts[b], cap)] for b in range(n)]
 
+    def object_points_batch_counts(self):
+        """the number of triangulated points of every frame of the batch (no copy, no synchronisation)"""
+        counts = (C.c_int * self.n)()
+        self._check(self._L.vo_get_object_points_batch(self._h, None, None, 0, counts))
+        return list(counts)
+
+    def object_points_batch_into(self, dst_ptr, cap):
+        """The same copy into caller memory at address dst_ptr, host or device (on this context's GPU): [n][cap][3] float32,
+        frame b's first min(k_b, cap) rows filled.  Returns the counts."""
+        counts = (C.c_int * self.n)()
+        self._check(self._L.vo_get_object_points_batch(self._h, C.c_void_p(dst_ptr), None, cap, counts))
+        return list(counts)
+
     def pnp_score(self, Rt12, thresh2=64.0, b=0, with_masks=False, k=None):
         Rt12 = np.ascontiguousarray(Rt12, dtype=np.float64).reshape(-1, 12)
         H = Rt12.shape[0]

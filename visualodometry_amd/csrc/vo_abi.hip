@@ -579,8 +579,8 @@ extern "C" int vo_get_object_points_batch(vo_ctx* c, vo_point3f* obj, vo_point2f
     for (int b = 0; b < c->n; b++) { kmax = std::max(kmax, c->h_nobj[b]); if (counts) counts[b] = c->h_nobj[b]; }
     const size_t w = (size_t)std::min(kmax, cap), F = c->p.max_features;
     if (w == 0) return VO_OK;
-    if (obj) VO_HIP(c, hipMemcpy2DAsync(obj, (size_t)cap * sizeof(vo_point3f), c->obj, F * sizeof(vo_point3f), w * sizeof(vo_point3f), c->n, hipMemcpyDeviceToHost, c->stream));
-    if (img2) VO_HIP(c, hipMemcpy2DAsync(img2, (size_t)cap * sizeof(vo_point2f), c->obj_img, F * sizeof(vo_point2f), w * sizeof(vo_point2f), c->n, hipMemcpyDeviceToHost, c->stream));
+    if (obj) VO_HIP(c, hipMemcpy2DAsync(obj, (size_t)cap * sizeof(vo_point3f), c->obj, F * sizeof(vo_point3f), w * sizeof(vo_point3f), c->n, hipMemcpyDefault, c->stream));
+    if (img2) VO_HIP(c, hipMemcpy2DAsync(img2, (size_t)cap * sizeof(vo_point2f), c->obj_img, F * sizeof(vo_point2f), w * sizeof(vo_point2f), c->n, hipMemcpyDefault, c->stream));
     VO_HIP(c, hipStreamSynchronize(c->stream));
     return VO_OK;
 }

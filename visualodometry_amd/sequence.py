@@ -113,32 +113,83 @@ def gather_trajectories(local, n_sequences, max_steps, group=None):
     return {i: buf[i, :int(cnt[i])].numpy().copy() for i in range(n_sequences) if int(cnt[i]) > 0}
 
 
-def gather_point_clouds(clouds, cap, group=None):
+_pinned = {}
+
+
+def _host_landing(shape, dtype, device):
+    """a host tensor for results coming off `device`: page-locked (and kept for the next call) when they come from a GPU"""
+    import torch
+    if device.type != "cuda":
+        return torch.empty(shape, dtype=dtype)
+    need = 1
+    for d in shape:
+        need *= int(d)
+    key = (dtype, device.index)
+    buf = _pinned.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(max(need, 1), dtype=dtype, pin_memory=True)
+        _pinned[key] = buf
+    return buf[:need].view(shape)
+
+
+def gather_point_clouds(clouds, cap, group=None, reserve=0):
     """clouds: this rank's list of [k_i, 3] float32 point sets (the triangulated points of its frame pairs, k_i <= cap), the
-    same number of sets on every rank.  One all_gather of the counts, then one of fixed-size buffers padded to the largest
-    count of any rank (not to `cap`: a KITTI-shape frame has about 4 000 points for a capacity of 16 384); returns, on every
-    rank, a list over ranks of lists of [k_i, 3] arrays."""
+    same number of sets on every rank; or a pair (buf, counts) with the sets already padded into ONE [n, k, 3] float32 torch
+    tensor (on the collective's device: the points then never visit the host before the gather) and their counts.  One
+    all_gather of the counts, then one of fixed-size buffers padded to the largest count of any rank (not to `cap`: a
+    KITTI-shape frame has about 4 000 points for a capacity of 16 384); returns, on every rank, a list over ranks of lists of
+    [k_i, 3] arrays.  reserve: points per set to size the page-locked landing buffer for (a first call made for set-up passes
+    the capacity, so that later calls allocate nothing)."""
     import torch
     import torch.distributed as dist
-    n = len(clouds)
-    arrs = [np.asarray(pts, dtype=np.float32).reshape(-1, 3) for pts in clouds]
-    for i, a in enumerate(arrs):
-        if a.shape[0] > cap:
-            raise ValueError("point set %d has %d points, capacity %d" % (i, a.shape[0], cap))
-    if not dist.is_initialized():
-        return [[a.copy() for a in arrs]]
+    padded = isinstance(clouds, tuple)
+    if padded:
+        pbuf, counts = clouds
+        n = len(counts)
+        if pbuf.dim() != 3 or pbuf.shape[0] != n or pbuf.shape[2] != 3 or pbuf.dtype != torch.float32:
+            raise ValueError("padded point sets must be one [n, k, 3] float32 tensor")
+        counts = [int(c) for c in counts]
+        if any(c > cap for c in counts):
+            raise ValueError("a point set has %d points, capacity %d" % (max(counts), cap))
+        if not dist.is_initialized():
+            host = pbuf.cpu().numpy()
+            return [[host[i, :min(counts[i], host.shape[1])].copy() for i in range(n)]]
+    else:
+        n = len(clouds)
+        arrs = [np.asarray(pts, dtype=np.float32).reshape(-1, 3) for pts in clouds]
+        for i, a in enumerate(arrs):
+            if a.shape[0] > cap:
+                raise ValueError("point set %d has %d points, capacity %d" % (i, a.shape[0], cap))
+        if not dist.is_initialized():
+            return [[a.copy() for a in arrs]]
+        counts = [a.shape[0] for a in arrs]
     world = dist.get_world_size(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    cnt = torch.tensor([a.shape[0] for a in arrs], dtype=torch.int64).to(dev)
+    cnt = torch.tensor(counts, dtype=torch.int64).to(dev)
     cnts = [torch.empty_like(cnt) for _ in range(world)]
     dist.all_gather(cnts, cnt, group=group)
     cnts = [c.cpu() for c in cnts]
     kmax = max(1, max(int(c.max()) if c.numel() else 0 for c in cnts))
-    buf = torch.zeros((n, kmax, 3), dtype=torch.float32)
-    for i, a in enumerate(arrs):
-        buf[i, :a.shape[0]] = torch.from_numpy(a)
-    buf = buf.to(dev)
+    if padded:
+        buf = pbuf.to(dev)
+        if buf.shape[1] > kmax:
+            buf = buf[:, :kmax]
+        elif buf.shape[1] < kmax:   # another rank has a larger set
+            buf = torch.nn.functional.pad(buf, (0, 0, 0, kmax - buf.shape[1]))
+        buf = buf.contiguous()
+    else:
+        buf = torch.zeros((n, kmax, 3), dtype=torch.float32)
+        for i, a in enumerate(arrs):
+            buf[i, :a.shape[0]] = torch.from_numpy(a)
+        buf = buf.to(dev)
     bufs = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(bufs, buf, group=group)
-    bufs = [x.cpu().numpy() for x in bufs]
-    return [[bufs[r][i, :int(cnts[r][i])].copy() for i in range(n)] for r in range(world)]
+    if reserve:
+        _host_landing((world, n, max(reserve, kmax), 3), torch.float32, dev)
+    host = _host_landing((world, n, kmax, 3), torch.float32, dev)
+    for r in range(world):
+        host[r].copy_(bufs[r], non_blocking=True)
+    if dev.type == "cuda":
+        torch.cuda.current_stream().synchronize()
+    host = host.numpy().copy()   # the landing buffer is reused by the next call
+    return [[host[r, i, :int(cnts[r][i])] for i in range(n)] for r in range(world)]
