@@ -14,6 +14,8 @@ C="--frame-cache /tmp/vo_frames"   # rendered once by the first (unprofiled) run
 # profiled runs: one batch size only (no one-pair latency pass), no communicator, no CPU or upload legs
 P="--no-cpu --no-upload-leg --no-latency --no-collective"
 timeout -k 10 300 python3 $B $C > $out/bench_default.json 2> $out/bench_default.err
+# the short run the round-end driver makes (its fill, drain and result gather weigh 5-7 % at 20 steps)
+timeout -k 10 300 python3 $B $C --steps 20 --warmup 5 > $out/bench_steps20.json 2> $out/bench_steps20.err
 timeout -k 10 100 python3 $B $C --inflight 1 --steps 1 --warmup 0 $P > /dev/null 2>&1   # fills the frame cache of the one-batch-in-flight passes
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d $out -o default --output-format csv -- python3 $B $C $P > $out/default.log 2>&1
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d $out -o inflight1 --output-format csv -- python3 $B $C $P --steps 10 --warmup 2 --inflight 1 > $out/inflight1.log 2>&1

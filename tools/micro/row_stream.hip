@@ -8,6 +8,9 @@
 //   v3  v0 with 16 columns per group;
 //   v4  v1 with the group of 8 columns requested TWO groups ahead;
 //   v5  v0 plus the checkpoint pass's stores (16 bytes per lane every 16 columns), v6 the same with non-temporal stores;
+//   v7-v13  the same stores in other shapes (one KiB contiguous per wavefront, 12 bytes per lane, four segments per burst, one
+//       dwordx4, a quarter of them, into 1 MiB that stays in cache, 4 bytes per lane), v14 with no branch in the loop,
+//   v15/v16  on a volume with a checkpoint slot behind every 16 columns of a row: stores elsewhere / into those slots;
 // each with a trivial consumer (xor).  hipcc --offload-arch=gfx950 -O3 -o row_stream tools/micro/row_stream.hip && ./row_stream
 #include <hip/hip_runtime.h>
 #include <stdio.h>
