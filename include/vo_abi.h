@@ -86,6 +86,13 @@ typedef struct {
      * as modes 1, 4 (NEON) and 8 (x86) of the same field, where 99.9 % of the tracks stay within 0.01 px of mode 0 and no
      * relative pose moves by more than 5e-7 rad / 2e-5 m.  Any other value here: VO_ERR_UNSUPPORTED from vo_create. */
     int lk_accum;             /* 0 */
+    /* Where the 5-point minimal solves of the RANSAC rounds run.  0: on the host's worker threads (the reference's split:
+     * only hypothesis scoring is batched on the GPU).  1: on the GPU, one thread per hypothesis, from the correspondences that
+     * are already in device memory (the host still draws the subsets from OpenCV's generator, replays the sequential accept
+     * rule and runs the final iterative solve).  Same arithmetic in the same order; a hypothesis can differ from the host's in
+     * the last bits through the device's hypot / acos / sin / cos.  For workloads whose solves outrun the host
+     * (1 024 hypotheses per frame) and for nodes with few cores per GPU. */
+    int pnp_device;           /* 0 */
 } vo_params;
 
 typedef struct {
@@ -247,7 +254,7 @@ int vo_pyramid_info(vo_ctx* ctx, int level, int* w, int* h, int* max_level);
 #define VO_NUM_STAGES 16
 typedef enum {
     VO_ST_PREFILTER = 0, /* 1: not in use */ VO_ST_VPATH = 2, VO_ST_HPATH_FWD = 3, VO_ST_HPATH_BWD = 4, VO_ST_LRCHECK = 5 /* consistency check + median */,
-    /* 6: not in use */ VO_ST_FAST = 7, VO_ST_PYRAMID = 8, VO_ST_LK = 9, VO_ST_FILTER = 10, VO_ST_TRIANGULATE = 11,
+    VO_ST_PNP_SOLVE = 6 /* minimal solves on the GPU (pnp_device = 1) */, VO_ST_FAST = 7, VO_ST_PYRAMID = 8, VO_ST_LK = 9, VO_ST_FILTER = 10, VO_ST_TRIANGULATE = 11,
     VO_ST_PNP_SCORE = 12, VO_ST_PNP_HOST = 13, VO_ST_STEP_WALL = 14,
     VO_ST_PNP_SERIAL = 15 /* host solver sections that found the process's worker pool busy with another thread's section and ran
                            * on the calling thread alone (one pool per process, shared by its contexts) */
@@ -266,6 +273,8 @@ const char* vo_stage_name(int stage);
  * vo_host_rng_subsets: the first nsubsets 5-index subsets cv::RNG((uint64)-1) yields for `count` points.
  * vo_host_rodrigues: rotation vector -> 3x3 matrix. */
 int vo_host_epnp(const vo_point3f* obj, const vo_point2f* img, int n, const double K[9], double rvec[3], double tvec[3]);
+/* the fixed-size 5-point form of the same solve that the GPU runs with pnp_device = 1, compiled for the host */
+int vo_host_epnp5_fixed(const vo_point3f* obj /* 5 */, const vo_point2f* img /* 5 */, const double K[9], double rvec[3], double tvec[3]);
 int vo_host_pnp_iterative(const double* obj, const double* img, int n, const double K[9], double rvec[3], double tvec[3]);
 int vo_host_p3p(const vo_point3f* obj /* 4 */, const vo_point2f* img /* 4 */, const double K[9], double rvec[3], double tvec[3]);
 int vo_host_rng_subsets(int count, int nsubsets, int* idx_out /* nsubsets*5 */);

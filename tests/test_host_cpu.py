@@ -88,6 +88,19 @@ def test_host_epnp_matches_oracle_bitwise():
     assert np.array_equal(r, orr) and np.array_equal(t, ot)
 
 
+def test_fixed_size_epnp_is_the_host_solver_bit_for_bit():
+    """epnp5.h is what the GPU runs with pnp_device = 1; compiled for the host it must be pnp_host::epnp's arithmetic."""
+    lib = abi.lib()
+    Kc = np.ascontiguousarray(K)
+    for seed in range(300):
+        obj, img = scene(5, 500 + seed, noise=0.1 * (seed % 9))
+        r, t, rf, tf = np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3)
+        assert lib.vo_host_epnp(_ptr(obj), _ptr(img), 5, _ptr(Kc), _ptr(r), _ptr(t)) == 0
+        assert lib.vo_host_epnp5_fixed(_ptr(obj), _ptr(img), _ptr(Kc), _ptr(rf), _ptr(tf)) == 0
+        assert np.array_equal(r, rf) and np.array_equal(t, tf), seed
+    assert lib.vo_host_epnp5_fixed(None, _ptr(img), _ptr(Kc), _ptr(rf), _ptr(tf)) == -1
+
+
 def test_host_iterative_matches_oracle_bitwise():
     lib = abi.lib()
     Kc = np.ascontiguousarray(K)

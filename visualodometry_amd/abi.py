@@ -25,7 +25,7 @@ EXPORTS = (
     "vo_match_klt", "vo_get_matches", "vo_get_klt_legs", "vo_set_matches", "vo_triangulate", "vo_get_object_points", "vo_get_object_points_batch",
     "vo_pnp_score", "vo_estimate_motion", "vo_integrate_pose", "vo_step", "vo_step_submit", "vo_step_finish", "vo_read_tap", "vo_pyramid_info",
     "vo_set_timing", "vo_get_timing", "vo_stage_name",
-    "vo_host_epnp", "vo_host_pnp_iterative", "vo_host_p3p", "vo_host_rng_subsets", "vo_host_rodrigues",
+    "vo_host_epnp", "vo_host_epnp5_fixed", "vo_host_pnp_iterative", "vo_host_p3p", "vo_host_rng_subsets", "vo_host_rodrigues",
 )
 NUM_STAGES = 16
 # vo_cloud_point
@@ -51,7 +51,7 @@ class Params(C.Structure):
         ("lk_epsilon", C.c_double), ("lk_min_eig", C.c_double),
         ("loop_threshold", C.c_int), ("depth_thresh", C.c_int),
         ("ransac_iters", C.c_int), ("ransac_reproj", C.c_float), ("ransac_conf", C.c_double),
-        ("ransac_chunk", C.c_int), ("host_threads", C.c_int), ("lk_accum", C.c_int),
+        ("ransac_chunk", C.c_int), ("host_threads", C.c_int), ("lk_accum", C.c_int), ("pnp_device", C.c_int),
     ]
 
 

@@ -1,6 +1,7 @@
 // Host-side minimal solvers and RANSAC bookkeeping (see pnp_host.h).  f64, compiled without FP contraction.
 #include "pnp_host.h"
 #include "small_linalg.h"
+#include "epnp5.h"
 #include <math.h>
 #include <string.h>
 #include <array>
@@ -366,6 +367,11 @@ void epnp(const vo_point3f* obj, const vo_point2f* img, int n, const double K[9]
     double R[9];
     for (int i = 0; i < 3; i++) { tvec[i] = ts[N][i]; for (int j = 0; j < 3; j++) R[i * 3 + j] = Rs[N][i][j]; }
     rodrigues_from_matrix(R, rvec);
+}
+
+void epnp5_fixed(const vo_point3f* obj, const vo_point2f* img, const double K[9], double rvec[3], double tvec[3])
+{
+    epnp5::solve(obj, img, K, rvec, tvec);
 }
 
 // ------------------------------------------------------------------ iterative PnP: DLT start + Levenberg-Marquardt
@@ -922,6 +928,8 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
     }
 
     double* h_hyp = (double*)c->h_stage;                         // [n][chunk][12]
+    const bool on_device = c->p.pnp_device != 0;
+    double* h_rt6 = (double*)c->h_stage;                         // GPU solves: [n][chunk][6] rvec, tvec (the subsets sit behind them)
     int* h_cnt = (int*)((char*)c->h_stage + (size_t)n * chunk * 12 * sizeof(double)); // [n][chunk]
     // inlier masks of a round's hypotheses, [n][chunk][kmax] bytes: fetched together with the counts (one strided copy, one
     // wait per round) rather than per frame after the counts have been looked at
@@ -942,6 +950,23 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
             f.nh = std::min(chunk, f.niters - f.iter);
             for (int h = 0; h < f.nh; h++) draw_subset(f.rng, f.k, model_points, f.idx[h].data());
         }
+        if (on_device) {
+            // minimal solves on the GPU: the subsets go up, the kernel reads the correspondences where the triangulation left
+            // them, and only the rotation / translation vectors come back (a new best model keeps them)
+            int* h_idx = (int*)((char*)c->h_stage + (size_t)n * chunk * 6 * sizeof(double)); // [n][chunk][5], then [n] counts
+            int* h_nh = h_idx + (size_t)n * chunk * 5;
+            for (int b = 0; b < n; b++) {
+                const FrameRansac& f = fr[b];
+                h_nh[b] = f.nh;
+                for (int h = 0; h < chunk; h++) // slots beyond a frame's hypotheses repeat its first one (scored and ignored)
+                    memcpy(h_idx + ((size_t)b * chunk + h) * 5, f.idx[h < f.nh ? h : 0].data(), 5 * sizeof(int));
+            }
+            VO_HIP(c, hipMemcpyAsync(c->hyp_idx, h_idx, (size_t)n * chunk * 5 * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            VO_HIP(c, hipMemcpyAsync(c->hyp_idx + (size_t)c->p.max_batch * chunk * 5, h_nh, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            const int rs = launch_pnp_solve(c, n);
+            if (rs) return rs;
+            VO_HIP(c, hipMemcpyAsync(h_rt6, c->hyp_rt, (size_t)n * chunk * 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        } else {
         parallel_for(c, n * chunk, threads, [&](int t) {
             const int b = t / chunk, h = t - b * chunk;
             FrameRansac& f = fr[b];
@@ -960,7 +985,10 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
                 memcpy(h_hyp + ((size_t)b * chunk + h) * 12, h_hyp + ((size_t)b * chunk) * 12, 12 * sizeof(double));
         // GPU: score every hypothesis of every frame against all of that frame's correspondences
         VO_HIP(c, hipMemcpyAsync(c->hyp, h_hyp, (size_t)n * chunk * 12 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        int rc = launch_pnp_score(c, 0, n, chunk, thresh2, true);
+        }
+        // masks of every hypothesis only when they can ride to the host with the counts; otherwise the scoring pass writes none
+        // (a byte per hypothesis and point is most of its memory traffic) and a second pass writes the new best models' masks
+        int rc = launch_pnp_score(c, 0, n, chunk, thresh2, masks_fit);
         if (rc) return rc;
         VO_HIP(c, hipMemcpyAsync(h_cnt, c->hyp_count, (size_t)n * chunk * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         if (masks_fit && kmax > 0)
@@ -974,7 +1002,10 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
                 const int good = h_cnt[(size_t)b * chunk + h];
                 if (good > std::max(f.max_good, model_points - 1)) {
                     f.max_good = good; f.best_h = h;
-                    memcpy(f.best_r, f.hr[h].data(), sizeof(f.best_r)); memcpy(f.best_t, f.ht[h].data(), sizeof(f.best_t));
+                    if (on_device) {
+                        const double* rt = h_rt6 + ((size_t)b * chunk + h) * 6;
+                        memcpy(f.best_r, rt, sizeof(f.best_r)); memcpy(f.best_t, rt + 3, sizeof(f.best_t));
+                    } else { memcpy(f.best_r, f.hr[h].data(), sizeof(f.best_r)); memcpy(f.best_t, f.ht[h].data(), sizeof(f.best_t)); }
                     f.niters = update_num_iters(c->p.ransac_conf, (double)(f.k - good) / f.k, model_points, f.niters);
                 }
                 f.iter++;
@@ -982,13 +1013,20 @@ static int estimate_motion_rounds(vo_ctx* c, double* Rt_out, vo_frame_info* info
         }
         // inlier mask of each frame's new best model
         bool fetch = false;
+        for (int b = 0; b < n; b++) fetch = fetch || (fr[b].best_h >= 0 && !masks_fit);
+        if (fetch) {
+            int* h_sel = h_cnt; // the counts have been consumed
+            for (int b = 0; b < n; b++) h_sel[b] = fr[b].best_h;
+            VO_HIP(c, hipMemcpyAsync(c->hyp_sel, h_sel, (size_t)n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            rc = launch_pnp_masks(c, n, thresh2);
+            if (rc) return rc;
+        }
         for (int b = 0; b < n; b++) {
             FrameRansac& f = fr[b];
             if (f.best_h < 0) continue;
             f.best_mask.resize(f.k);
             if (masks_fit) { memcpy(f.best_mask.data(), h_mask + ((size_t)b * chunk + f.best_h) * kmax, (size_t)f.k); continue; }
             VO_HIP(c, hipMemcpyAsync(f.best_mask.data(), c->hyp_mask + ((size_t)b * chunk + f.best_h) * F, (size_t)f.k, hipMemcpyDeviceToHost, c->stream));
-            fetch = true;
         }
         if (fetch) VO_HIP(c, hipStreamSynchronize(c->stream));
     }

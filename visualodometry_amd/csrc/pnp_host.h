@@ -25,6 +25,8 @@ bool inv4x4(const double* A, double* Ainv);
 
 // solvePnP(SOLVEPNP_EPNP) on float correspondences; K row-major 3x3
 void epnp(const vo_point3f* obj, const vo_point2f* img, int n, const double K[9], double rvec[3], double tvec[3]);
+// the same solve for exactly five correspondences on fixed-size arrays (epnp5.h, the code the GPU runs with pnp_device = 1)
+void epnp5_fixed(const vo_point3f* obj, const vo_point2f* img, const double K[9], double rvec[3], double tvec[3]);
 // solvePnP(SOLVEPNP_ITERATIVE) without an extrinsic guess on f64 correspondences.
 // (planar objects start from the plane's homography, others from the 12-parameter DLT);
 // returns 1, or -3 fewer than 6 points on a non-planar object, -4 degenerate

@@ -64,6 +64,7 @@ static int derive(vo_ctx* c)
     if (p.wta_simd_lanes != 0 && p.wta_simd_lanes != 8 && p.wta_simd_lanes != 16) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "wta_simd_lanes must be 0, 8 or 16");
     if (p.lk_win < 3 || p.lk_win > 31 || !(p.lk_win & 1)) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "lk_win must be odd in [3, 31]");
     if (p.lk_max_level < 0 || p.lk_max_level >= VO_MAX_LEVELS) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "lk_max_level out of range");
+    if (p.pnp_device != 0 && p.pnp_device != 1) return vo_fail(nullptr, VO_ERR_BAD_PARAM, "pnp_device must be 0 (host solves) or 1 (GPU solves)");
     if (p.lk_accum != 0) return vo_fail(nullptr, VO_ERR_UNSUPPORTED, "lk_accum %d: the tracker sums in exact integers (0); the float summation orders exist in the CPU oracle only", p.lk_accum);
     c->W = p.width; c->H = p.height; c->D = p.num_disparities; c->Dp = (c->D + 31) & ~31;
     c->width1 = c->W - c->D;
@@ -185,6 +186,11 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
     CR(dalloc(&c->hyp, B * c->p.ransac_chunk * 12));
     CR(dalloc(&c->hyp_count, B * c->p.ransac_chunk));
     CR(dalloc(&c->hyp_mask, B * c->p.ransac_chunk * F));
+    CR(dalloc(&c->hyp_sel, B));
+    if (c->p.pnp_device) {
+        CR(dalloc(&c->hyp_idx, B * c->p.ransac_chunk * 5 + B));
+        CR(dalloc(&c->hyp_rt, B * c->p.ransac_chunk * 6));
+    }
     // pinned staging: the correspondences of a batch ([B][F] points), later reused for a RANSAC round's hypotheses and
     // counts ([B][chunk] x (12 doubles + 1 int)); inlier masks ride along when they fit
     c->h_stage_bytes = std::max<size_t>(std::max<size_t>(B * F * (sizeof(vo_point3f) + sizeof(vo_point2f)) + B * 64,
@@ -204,7 +210,7 @@ extern "C" void vo_destroy(vo_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = {c->img_own, c->pre, c->cost, c->agg, c->wta, c->ckpt, c->disp_pre, c->disp16, c->disp32, c->depth, c->score,
                     c->row_count, c->kp_mask, c->n_feat, c->feat, c->pyr, c->der, c->legs, c->leg_status, c->m1, c->m2,
-                    c->obj, c->obj_img, c->hyp, c->hyp_count, c->hyp_mask};
+                    c->obj, c->obj_img, c->hyp, c->hyp_count, c->hyp_mask, c->hyp_sel, c->hyp_idx, c->hyp_rt};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (c->cloud) (void)hipFree(c->cloud);
     if (c->cloud_rows) (void)hipFree(c->cloud_rows);
@@ -703,7 +709,7 @@ extern "C" int vo_step(vo_ctx* c, double* Rt_out, vo_frame_info* info)
 }
 
 static const char* kStageNames[VO_NUM_STAGES] = {"sgbm_prefilter", "", "sgbm_cost_vpath", "sgbm_hpath_ckpt", "sgbm_hpath_resolve",
-    "sgbm_lrcheck_median", "", "fast", "pyramid", "lk", "klt_filter", "triangulate", "pnp_score", "pnp_host", "step_wall", "pnp_host_serial"};
+    "sgbm_lrcheck_median", "pnp_solve", "fast", "pyramid", "lk", "klt_filter", "triangulate", "pnp_score", "pnp_host", "step_wall", "pnp_host_serial"};
 
 extern "C" const char* vo_stage_name(int s) { return s >= 0 && s < VO_NUM_STAGES ? kStageNames[s] : ""; }
 
@@ -744,6 +750,13 @@ extern "C" int vo_host_epnp(const vo_point3f* obj, const vo_point2f* img, int n,
 {
     if (!obj || !img || !K || !rvec || !tvec || n < 4) return VO_ERR_BAD_ARG;
     pnp_host::epnp(obj, img, n, K, rvec, tvec);
+    return VO_OK;
+}
+
+extern "C" int vo_host_epnp5_fixed(const vo_point3f* obj, const vo_point2f* img, const double K[9], double rvec[3], double tvec[3])
+{
+    if (!obj || !img || !K || !rvec || !tvec) return VO_ERR_BAD_ARG;
+    pnp_host::epnp5_fixed(obj, img, K, rvec, tvec);
     return VO_OK;
 }
 

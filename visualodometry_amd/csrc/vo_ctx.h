@@ -98,6 +98,9 @@ struct vo_ctx {
     double* hyp = nullptr;       // [n][chunk][12]
     int* hyp_count = nullptr;    // [n][chunk]
     uint8_t* hyp_mask = nullptr; // [n][chunk][max_features]
+    int* hyp_sel = nullptr;      // [max_batch] hypothesis of a round whose inlier mask the host wants (mask pass)
+    int* hyp_idx = nullptr;      // pnp_device: [max_batch][chunk][5] subset indices, then [max_batch] hypotheses of the round per frame
+    double* hyp_rt = nullptr;    // pnp_device: [n][chunk][6] rvec, tvec of the round's hypotheses
     bool have_obj = false;
 
     // split step: GPU part enqueued, host part pending
@@ -157,5 +160,7 @@ int launch_pyramids(vo_ctx* c);
 int launch_match_klt(vo_ctx* c, bool counts_on_host);
 int launch_triangulate(vo_ctx* c);
 int launch_pnp_score(vo_ctx* c, int b0, int nb, int H, float thresh2, bool want_masks);
+int launch_pnp_masks(vo_ctx* c, int nb, float thresh2); // masks of hypothesis c->hyp_sel[b] of every frame
+int launch_pnp_solve(vo_ctx* c, int n); // pnp_solve.hip: 5-point solves of a round from c->hyp_idx into c->hyp and c->hyp_rt
 
 #endif
