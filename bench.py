@@ -369,11 +369,12 @@ def main(argv=None):
         # longer host part per batch (4.2 ms against 2.8 ms: its frame pools are walked in both directions and the harder pairs
         # take more solver work), and a fourth batch covers it.
         args.inflight = 4 if args.workload == "kitti11" else 3
-    if args.inflight > 3:
-        # a process gets 4 hardware queues by default; with more streams than queues the batches serialise behind each other.
-        # (Under a profiler that initialises the runtime before main() the variable has to be exported in the shell instead.)
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(32, 2 * args.inflight)))
-        log("[bench] GPU_MAX_HW_QUEUES=%s for %d batches in flight" % (os.environ["GPU_MAX_HW_QUEUES"], args.inflight))
+    # A process gets 4 hardware queues by default.  Every batch in flight uses two streams (disparity chain, tracking chain) and
+    # all share one high-priority stream for the pose solver's round trips; with more streams than queues they serialise behind
+    # each other, so the run asks for 8 queues (2 per batch beyond three batches; the box refuses more than 32).
+    # (Under a profiler that initialises the runtime before main() the variable has to be exported in the shell instead.)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(32, max(8, 2 * args.inflight))))
+    log("[bench] GPU_MAX_HW_QUEUES=%s for %d batches in flight" % (os.environ["GPU_MAX_HW_QUEUES"], args.inflight))
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

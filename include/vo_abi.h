@@ -227,12 +227,15 @@ int vo_step(vo_ctx* ctx, double* Rt_out /* n*16 */, vo_frame_info* info /* nulla
  * solvers, final refine) of one batch with the GPU part of the next: vo_step_submit enqueues every GPU
  * stage and returns without waiting; vo_step_finish waits for them and runs the host part.
  * vo_step(ctx, ...) == vo_step_submit(ctx) followed by vo_step_finish(ctx, ...).
- * Streams: a context enqueues on one stream of its own; the pose solver's short round trips use one
- * high-priority stream shared by all contexts of a device.  A process has few hardware queues (4 unless
- * GPU_MAX_HW_QUEUES says otherwise), so three contexts in flight is the sweet spot for throughput.  A step of ONE frame
- * pair runs its corner / tracking chain on a second stream beside the disparity chain (a single pair leaves most of the
- * GPU idle: 2.2 -> 1.8 ms per step at KITTI shape); batches do that only with the environment variable VO_DUAL_STREAM set
- * when the context is created (no gain with three contexts in flight), and VO_SINGLE_STREAM turns it off altogether. */
+ * Streams: a context enqueues the disparity chain on one stream and the corner / tracking chain on a second one; the pose
+ * solver's short round trips use one high-priority stream shared by all contexts of a device.  A step of ONE frame pair
+ * leaves most of the GPU idle, so its tracker starts at once (2.2 -> 1.7 ms per step at KITTI shape).  In a batch every
+ * large kernel fills the GPU, and the tracker waits for the cost kernel, the other kernel bound by vector issue, so that it
+ * runs beside the horizontal path passes, which memory and latency bound (up to 128 disparities and a 15 x 15 tracking window;
+ * beyond, where one of the two dwarfs the other, a batch stays on one stream).  A process has 4 hardware queues unless
+ * GPU_MAX_HW_QUEUES (read when the runtime starts) says otherwise: three contexts in flight want 8 (5 860 -> 6 000 frames/s;
+ * with 4 the second stream neither helps nor hurts).  Environment, read by vo_create: VO_SINGLE_STREAM keeps a context on
+ * one stream, VO_DUAL_STREAM starts a batch's tracker at once as well. */
 int vo_step_submit(vo_ctx* ctx);
 int vo_step_finish(vo_ctx* ctx, double* Rt_out /* n*16 */, vo_frame_info* info /* nullable, n */);
 

@@ -900,6 +900,7 @@ int run_sgbm(vo_ctx* c)
                                SH2, c->srows, si, c->P1, c->P2, c->cost, c->agg, c->D, c->dead_cost);
     }
     }
+    if (c->after_cost) VO_HIP(c, hipEventRecord(c->after_cost, c->stream));
     const int nseg = vo_hpath_segments(c);
     { StageTimer st_(c, VO_ST_HPATH_FWD);
     hipLaunchKernelGGL((hpath_ckpt_kernel<NP>), dim3((H + 15) / 16, n), dim3(256), 0, c->stream, c->cost, w1, D, H, c->srows, si, c->stripe_sz,

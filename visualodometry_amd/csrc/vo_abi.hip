@@ -151,11 +151,13 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
         c->stream_hi = g_hi_stream[device];
         g_hi_users[device]++;
     }
+    // A second stream carries the corner / tracking chain of a step beside the disparity chain (see vo_step_submit)
     c->single_stream = getenv("VO_SINGLE_STREAM") != nullptr;
-    if (getenv("VO_DUAL_STREAM")) {
-        c->dual_always = true;
+    c->tracker_at_once = getenv("VO_DUAL_STREAM") != nullptr; // batches too start their tracker without waiting for the cost kernel
+    if (!c->single_stream) {
         CR(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         CR(hipEventCreateWithFlags(&c->join2, hipEventDisableTiming));
+        CR(hipEventCreateWithFlags(&c->after_cost, hipEventDisableTiming));
     }
     const size_t B = c->p.max_batch, W = c->W, H = c->H, D = c->Dp, w1 = c->width1, F = c->p.max_features;
     c->own_pitch = (W + 63) & ~(size_t)63; c->own_fstride = c->own_pitch * H;
@@ -224,6 +226,7 @@ extern "C" void vo_destroy(vo_ctx* c)
     }
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->join2) (void)hipEventDestroy(c->join2);
+    if (c->after_cost) (void)hipEventDestroy(c->after_cost);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -649,20 +652,21 @@ extern "C" int vo_step_submit(vo_ctx* c)
     // every GPU stage is enqueued back to back without a host round trip
     if ((rc = launch_sgbm(c))) return rc;
     c->have_disp = true; c->have_depth = false;
-    // disparity and the corner / tracking chain are independent until triangulation: with a second stream the
-    // instruction-bound tracker runs beside the bandwidth-bound cost volume passes of the same batch
-    // A single frame pair leaves most of the GPU idle (its kernels are serial along x or y): there the second stream is
-    // always worth it (2.2 -> 1.8 ms per step at KITTI shape) and is created on first use.  Batches fill the GPU by
-    // themselves and use it only on request (VO_DUAL_STREAM).
-    if (!c->stream2 && c->n == 1 && !c->single_stream) {
-        VO_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        VO_HIP(c, hipEventCreateWithFlags(&c->join2, hipEventDisableTiming));
-    }
+    // Disparity and the corner / tracking chain are independent until triangulation, so the second chain runs on a stream of
+    // its own.  A single frame pair leaves most of the GPU idle (its kernels are serial along x or y): its tracker starts at
+    // once (2.2 -> 1.7 ms per step at KITTI shape).  A batch fills the GPU with every large kernel, and two kernels bound by
+    // vector issue (cost kernel, tracker) gain nothing from sharing it: there the tracker waits for the cost kernel and runs
+    // beside the horizontal path passes, which are bound by memory and latency (5 900 -> 6 060 frames/s with 8 hardware queues,
+    // 5 950 with 4).  That pays where the two are of similar length, as at the reference's parameters; where one dwarfs the
+    // other the batch stays on one stream (measured: 4K x 256 disparities 174 -> 165 frames/s, 20 000 corners with a 21 x 21
+    // window 1 587 -> 1 531).  VO_SINGLE_STREAM keeps everything on one stream, VO_DUAL_STREAM starts a batch's tracker at once.
     hipStream_t main_stream = c->stream;
-    const bool dual = c->stream2 && (c->n == 1 || c->dual_always);
+    const bool dual = c->stream2 != nullptr && (c->n == 1 || c->tracker_at_once || (c->Dp <= 128 && c->p.lk_win <= 15));
     if (dual) c->stream = c->stream2;
     rc = launch_fast(c);
     if (!rc) rc = launch_pyramids(c);
+    if (!rc && dual && c->n > 1 && !c->tracker_at_once && hipStreamWaitEvent(c->stream, c->after_cost, 0) != hipSuccess)
+        rc = vo_fail(c, VO_ERR_HIP, "hipStreamWaitEvent failed");
     if (!rc) { c->have_pyr = true; rc = launch_match_klt(c, false); }
     if (dual) {
         if (!rc && hipEventRecord(c->join2, c->stream2) != hipSuccess) rc = vo_fail(c, VO_ERR_HIP, "hipEventRecord failed");

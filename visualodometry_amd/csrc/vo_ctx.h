@@ -27,7 +27,8 @@ struct vo_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // optional: corner / tracking chain of a step, beside the disparity chain on `stream`
     hipEvent_t join2 = nullptr;
-    bool dual_always = false, single_stream = false; // VO_DUAL_STREAM: second stream for every batch size; VO_SINGLE_STREAM: never
+    hipEvent_t after_cost = nullptr; // recorded behind the cost kernel: a batch's tracker on stream2 waits for it
+    bool tracker_at_once = false, single_stream = false; // VO_DUAL_STREAM: no such wait; VO_SINGLE_STREAM: no second stream
     hipStream_t stream_hi = nullptr; // highest priority: the short scoring round trips of the pose solver
     std::string err;
 
