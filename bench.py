@@ -699,10 +699,12 @@ def main(argv=None):
     isolated = {}
     if nctx > 1 and not stub:
         set_window(ctx, left.data_ptr(), right.data_ptr(), B)
+        ctx.set_timing(2)   # one stream: the tracking chain would otherwise share the GPU with the disparity chain
         ctx.timing(reset=True)
         for _ in range(3):
             ctx.step(strict=not args.lenient)
         isolated = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in ctx.timing().items()}
+        ctx.set_timing(1)
     # latency of one frame pair alone (batch of 1, one stream, nothing else in flight)
     latency_ms = None
     if not args.no_latency and not stub:

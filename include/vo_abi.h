@@ -253,7 +253,9 @@ int vo_pyramid_info(vo_ctx* ctx, int level, int* w, int* h, int* max_level);
 
 /* Optional per-stage timing (HIP events on the context's stream around each kernel group; host wall
  * clock for the host-side PnP part and the whole step).  ms: VO_NUM_STAGES accumulated milliseconds,
- * calls: how many times each stage ran since the last reset.  No counterpart in the reference. */
+ * calls: how many times each stage ran since the last reset.  enable = 2 also keeps every step on ONE stream, so that an
+ * interval holds its stage's kernels alone (with the tracking chain on its second stream, kernels of the two chains share
+ * the GPU and each other's intervals).  No counterpart in the reference. */
 #define VO_NUM_STAGES 16
 typedef enum {
     VO_ST_PREFILTER = 0, /* 1: not in use */ VO_ST_VPATH = 2, VO_ST_HPATH_FWD = 3, VO_ST_HPATH_BWD = 4, VO_ST_LRCHECK = 5 /* consistency check + median */,

@@ -7,7 +7,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 src=${VO_SRC:-$root/visualodometry_amd/csrc}
 out=$root/gpurun_variants
 mkdir -p $out/obj_$name
-for f in vo_abi fast sgbm lk pnp cloud; do
+for f in vo_abi fast sgbm lk pnp pnp_solve cloud; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off "$@" -c $src/$f.hip -o $out/obj_$name/$f.o &
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off "$@" -c $src/pnp_host.cpp -o $out/obj_$name/pnp_host.o &

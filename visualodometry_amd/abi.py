@@ -354,7 +354,8 @@ class Context:
 
     # --- per-stage timing
     def set_timing(self, enable=True):
-        self._check(self._L.vo_set_timing(self._h, int(bool(enable))))
+        """enable = 2: timing with every step on one stream (a stage's interval then holds its kernels alone)."""
+        self._check(self._L.vo_set_timing(self._h, int(enable)))
 
     def timing(self, reset=False):
         """{stage name: (accumulated ms, calls)}"""

@@ -661,7 +661,7 @@ extern "C" int vo_step_submit(vo_ctx* c)
     // other the batch stays on one stream (measured: 4K x 256 disparities 174 -> 165 frames/s, 20 000 corners with a 21 x 21
     // window 1 587 -> 1 531).  VO_SINGLE_STREAM keeps everything on one stream, VO_DUAL_STREAM starts a batch's tracker at once.
     hipStream_t main_stream = c->stream;
-    const bool dual = c->stream2 != nullptr && (c->n == 1 || c->tracker_at_once || (c->Dp <= 128 && c->p.lk_win <= 15));
+    const bool dual = c->stream2 != nullptr && !c->timing_exclusive && (c->n == 1 || c->tracker_at_once || (c->Dp <= 128 && c->p.lk_win <= 15));
     if (dual) c->stream = c->stream2;
     rc = launch_fast(c);
     if (!rc) rc = launch_pyramids(c);
@@ -725,6 +725,7 @@ extern "C" int vo_set_timing(vo_ctx* c, int enable)
         for (int i = 0; i < VO_NUM_STAGES; i++) { VO_HIP(c, hipEventCreate(&c->ev0[i])); VO_HIP(c, hipEventCreate(&c->ev1[i])); }
     }
     c->timing = enable != 0;
+    c->timing_exclusive = enable == 2;
     return VO_OK;
 }
 

@@ -116,6 +116,7 @@ struct vo_ctx {
 
     // optional per-stage timing with HIP events on the context's stream
     bool timing = false;
+    bool timing_exclusive = false; // steps stay on one stream, so that a stage's interval holds that stage's kernels alone
     hipEvent_t ev0[VO_NUM_STAGES], ev1[VO_NUM_STAGES];
     bool ev_used[VO_NUM_STAGES];
     double stage_ms[VO_NUM_STAGES];
