@@ -369,11 +369,15 @@ def main(argv=None):
         # longer host part per batch (4.2 ms against 2.8 ms: its frame pools are walked in both directions and the harder pairs
         # take more solver work), and a fourth batch covers it.
         args.inflight = 4 if args.workload == "kitti11" else 3
-    # A process gets 4 hardware queues by default.  Every batch in flight uses two streams (disparity chain, tracking chain) and
-    # all share one high-priority stream for the pose solver's round trips; with more streams than queues they serialise behind
-    # each other, so the run asks for 8 queues (2 per batch beyond three batches; the box refuses more than 32).
+    # A process gets 4 hardware queues by default.  At the reference's parameters every batch in flight uses two streams
+    # (disparity chain, tracking chain) and all share one high-priority stream for the pose solver's round trips; with more
+    # streams than queues they serialise behind each other, so those runs ask for 8 queues (5 950 -> 6 060 frames/s; 2 per
+    # batch beyond three batches; the box refuses more than 32).  The 4K and dense-tracking workloads keep a batch on one
+    # stream and are faster with the default 4 (4K: 174 against 162 frames/s with 8: more of the three batches' kernels
+    # share the GPU and each other's caches).
     # (Under a profiler that initialises the runtime before main() the variable has to be exported in the shell instead.)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(32, max(8, 2 * args.inflight))))
+    queues = max(8, 2 * args.inflight) if args.workload in ("kitti", "kitti11") else max(4, 2 * args.inflight if args.inflight > 3 else 4)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(32, queues)))
     log("[bench] GPU_MAX_HW_QUEUES=%s for %d batches in flight" % (os.environ["GPU_MAX_HW_QUEUES"], args.inflight))
 
     rank = int(os.environ.get("RANK", 0))

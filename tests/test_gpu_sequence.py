@@ -138,3 +138,29 @@ def test_chunk_of_a_sequence_equals_the_slice_of_the_whole(frames5):
     assert part.shape == (2, 4, 4) and len(info) == 2
     assert np.array_equal(part, whole[1:3])
     ctx.close()
+
+
+def test_stream_schedules_give_identical_results(monkeypatch):
+    """A batch's tracking chain runs on a second stream behind the cost kernel by default; VO_SINGLE_STREAM keeps a context on
+    one stream and VO_DUAL_STREAM starts the tracker at once (both read by vo_create).  Same kernels, same results."""
+    W, H, nb = 640, 192, 5
+    seq = synth.Sequence(seed=1011, width=W, height=H)
+    frames = [seq.frame(i) for i in range(nb + 1)]
+    left = np.stack([f[0] for f in frames]); right = np.stack([f[1] for f in frames])
+    outs = []
+    for env in (None, "VO_SINGLE_STREAM", "VO_DUAL_STREAM"):
+        monkeypatch.delenv("VO_SINGLE_STREAM", raising=False); monkeypatch.delenv("VO_DUAL_STREAM", raising=False)
+        if env:
+            monkeypatch.setenv(env, "1")
+        ctx = abi.Context(abi.default_params(W, H, max_batch=nb, num_disparities=64, max_features=4096))
+        ctx.set_calib(seq.P0, seq.P1)
+        ctx.set_sequence(left, right)
+        for _ in range(2):   # a second step on the same context: the streams' events are reused
+            Rt, info = ctx.step()
+        outs.append((Rt.copy(), [ctx.disparity16(b).copy() for b in range(nb)], [ctx.matches(b)[0].copy() for b in range(nb)],
+                     [(i.n_features, i.n_matched, i.n_object_points, i.best_inliers) for i in info]))
+        ctx.close()
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and o[3] == outs[0][3]
+        for b in range(nb):
+            assert np.array_equal(o[1][b], outs[0][1][b]) and np.array_equal(o[2][b], outs[0][2][b])
