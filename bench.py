@@ -320,6 +320,7 @@ def parse_args(argv):
                     help="frame pairs of the CPU baseline's sample (default: 48 at KITTI shape, about 10 s on 16 threads; 1 at 4K)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0: 8 at KITTI shape, else 4; at most 32)")
     ap.add_argument("--pnp-device", type=int, default=None, choices=(0, 1),
                     help="RANSAC minimal solves on the host (0) or on the GPU (1); default: GPU for the dense workload, host otherwise")
     ap.add_argument("--inflight", type=int, default=0,
@@ -371,13 +372,13 @@ def main(argv=None):
         args.inflight = 4 if args.workload == "kitti11" else 3
     # A process gets 4 hardware queues by default.  At the reference's parameters every batch in flight uses two streams
     # (disparity chain, tracking chain) and all share one high-priority stream for the pose solver's round trips; with more
-    # streams than queues they serialise behind each other, so those runs ask for 8 queues (5 950 -> 6 060 frames/s; 2 per
+    # streams than queues they serialise behind each other, so those runs ask for 8 queues (5 880 -> 5 995 frames/s; 2 per
     # batch beyond three batches; the box refuses more than 32).  The 4K and dense-tracking workloads keep a batch on one
-    # stream and are faster with the default 4 (4K: 174 against 162 frames/s with 8: more of the three batches' kernels
-    # share the GPU and each other's caches).
+    # stream, gain nothing from more queues (167.5 against 166, 1 553 against 1 546 frames/s) and keep 4.
     # (Under a profiler that initialises the runtime before main() the variable has to be exported in the shell instead.)
-    queues = max(8, 2 * args.inflight) if args.workload in ("kitti", "kitti11") else max(4, 2 * args.inflight if args.inflight > 3 else 4)
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(32, queues)))
+    # The variable is set here whatever the environment holds (machines export HIP's default of 4); --hw-queues N chooses another.
+    queues = args.hw_queues if args.hw_queues > 0 else (max(8, 2 * args.inflight) if args.workload in ("kitti", "kitti11") else max(4, 2 * args.inflight if args.inflight > 3 else 4))
+    os.environ["GPU_MAX_HW_QUEUES"] = str(min(32, queues))
     log("[bench] GPU_MAX_HW_QUEUES=%s for %d batches in flight" % (os.environ["GPU_MAX_HW_QUEUES"], args.inflight))
 
     rank = int(os.environ.get("RANK", 0))

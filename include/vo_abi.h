@@ -234,7 +234,7 @@ int vo_step(vo_ctx* ctx, double* Rt_out /* n*16 */, vo_frame_info* info /* nulla
  * large kernel fills the GPU, and the tracker waits for the cost kernel, the other kernel bound by vector issue, so that it
  * runs beside the horizontal path passes, which memory and latency bound (up to 128 disparities and a 15 x 15 tracking window;
  * beyond, where one of the two dwarfs the other, a batch stays on one stream).  A process has 4 hardware queues unless
- * GPU_MAX_HW_QUEUES (read when the runtime starts) says otherwise: three contexts in flight want 8 (5 860 -> 6 000 frames/s;
+ * GPU_MAX_HW_QUEUES (read when the runtime starts) says otherwise: three contexts in flight want 8 (5 850 -> 5 995 frames/s;
  * with 4 the second stream neither helps nor hurts).  Environment, read by vo_create: VO_SINGLE_STREAM keeps a context on
  * one stream, VO_DUAL_STREAM starts a batch's tracker at once as well. */
 int vo_step_submit(vo_ctx* ctx);

@@ -30,7 +30,7 @@ def _rot_angle(Ra, Rb):
     return float(np.arccos(min(1.0, max(-1.0, c))))
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(ransac_iters=256, ransac_chunk=256)], ids=["rounds_of_8", "one_round_of_256_mask_pass"])
+@pytest.mark.parametrize("kw", [dict(), dict(ransac_iters=512, ransac_chunk=512)], ids=["rounds_of_8", "one_round_of_512_mask_pass"])
 def test_gpu_minimal_solves_match_host_and_oracle(kw):
     nb = 3
     seq = synth.Sequence(seed=1007, width=W, height=H)

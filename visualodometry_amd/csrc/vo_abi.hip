@@ -151,14 +151,11 @@ extern "C" int vo_create(const vo_params* p, int device, vo_ctx** out)
         c->stream_hi = g_hi_stream[device];
         g_hi_users[device]++;
     }
-    // A second stream carries the corner / tracking chain of a step beside the disparity chain (see vo_step_submit)
+    // A second stream can carry the corner / tracking chain of a step beside the disparity chain (see vo_step_submit).  It is
+    // created by the first step that uses it: a stream that is never used still takes a share of the process's few hardware
+    // queues, and two contexts' bulk streams on one queue serialise their batches.
     c->single_stream = getenv("VO_SINGLE_STREAM") != nullptr;
     c->tracker_at_once = getenv("VO_DUAL_STREAM") != nullptr; // batches too start their tracker without waiting for the cost kernel
-    if (!c->single_stream) {
-        CR(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
-        CR(hipEventCreateWithFlags(&c->join2, hipEventDisableTiming));
-        CR(hipEventCreateWithFlags(&c->after_cost, hipEventDisableTiming));
-    }
     const size_t B = c->p.max_batch, W = c->W, H = c->H, D = c->Dp, w1 = c->width1, F = c->p.max_features;
     c->own_pitch = (W + 63) & ~(size_t)63; c->own_fstride = c->own_pitch * H;
     CR(dalloc(&c->img_own, 4 * B * c->own_fstride));
@@ -649,6 +646,12 @@ extern "C" int vo_step_submit(vo_ctx* c)
     VO_HIP(c, hipSetDevice(c->device));
     c->step_t0 = std::chrono::steady_clock::now();
     int rc;
+    const bool dual = !c->single_stream && !c->timing_exclusive && (c->n == 1 || c->tracker_at_once || (c->Dp <= 128 && c->p.lk_win <= 15));
+    if (dual && !c->stream2) { // see below
+        VO_HIP(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        VO_HIP(c, hipEventCreateWithFlags(&c->join2, hipEventDisableTiming));
+        VO_HIP(c, hipEventCreateWithFlags(&c->after_cost, hipEventDisableTiming));
+    }
     // every GPU stage is enqueued back to back without a host round trip
     if ((rc = launch_sgbm(c))) return rc;
     c->have_disp = true; c->have_depth = false;
@@ -656,12 +659,11 @@ extern "C" int vo_step_submit(vo_ctx* c)
     // its own.  A single frame pair leaves most of the GPU idle (its kernels are serial along x or y): its tracker starts at
     // once (2.2 -> 1.7 ms per step at KITTI shape).  A batch fills the GPU with every large kernel, and two kernels bound by
     // vector issue (cost kernel, tracker) gain nothing from sharing it: there the tracker waits for the cost kernel and runs
-    // beside the horizontal path passes, which are bound by memory and latency (5 900 -> 6 060 frames/s with 8 hardware queues,
-    // 5 950 with 4).  That pays where the two are of similar length, as at the reference's parameters; where one dwarfs the
+    // beside the horizontal path passes, which are bound by memory and latency (5 850 -> 5 995 frames/s with 8 hardware queues,
+    // 5 885 with 4).  That pays where the two are of similar length, as at the reference's parameters; where one dwarfs the
     // other the batch stays on one stream (measured: 4K x 256 disparities 174 -> 165 frames/s, 20 000 corners with a 21 x 21
     // window 1 587 -> 1 531).  VO_SINGLE_STREAM keeps everything on one stream, VO_DUAL_STREAM starts a batch's tracker at once.
     hipStream_t main_stream = c->stream;
-    const bool dual = c->stream2 != nullptr && !c->timing_exclusive && (c->n == 1 || c->tracker_at_once || (c->Dp <= 128 && c->p.lk_win <= 15));
     if (dual) c->stream = c->stream2;
     rc = launch_fast(c);
     if (!rc) rc = launch_pyramids(c);
