@@ -495,13 +495,18 @@ def main(argv=None):
     def run_steps(k, upload=False):
         """k whole batches through the path, pipeline fill and drain included; returns the last batch's results"""
         out = None
+        trace = [time.perf_counter()] if os.environ.get("VO_BENCH_TRACE") else None
         for s in range(min(nctx, k)):
             submit_window(ctxs[s], s, upload)
         for s in range(k):
             c = ctxs[s % nctx]
             out = c.step_finish(strict=not args.lenient)
+            if trace is not None:
+                trace.append(time.perf_counter())
             if s + nctx < k:
                 submit_window(c, s + nctx, upload)
+        if trace is not None:   # when each step's results were in hand, ms after the first submit
+            log("[trace] steps finished at ms: " + " ".join("%.2f" % ((t - trace[0]) * 1e3) for t in trace[1:]))
         return out
 
     # ---- strong-scaling workload: the 11 KITTI-shaped sequences
