@@ -93,3 +93,47 @@ def test_gpu_minimal_solves_over_the_200_frame_sequence():
     assert float(np.abs(traj - fx["trajectory"]).max()) <= 1e-3 * float(fx["path_length"])
     assert same >= 0.95 * (NF - 1), same
     print("GPU minimal solves: %d of %d steps with the oracle's exact iteration and inlier counts" % (same, NF - 1))
+
+
+def test_gpu_minimal_solves_in_a_mixed_batch():
+    """A batch (shorter than the context's capacity) whose frames reach every branch around the rounds: many correspondences
+    (RANSAC rounds, solved on the GPU), exactly five and exactly four (one direct solve on the host, no rounds) and three
+    (refused).  The frames without rounds must come out exactly as with host solves, the one with rounds within tolerance."""
+    from scipy.spatial.transform import Rotation
+    P0, P1 = synth.calib(W, H)
+    fx, cx, cy = P0[0, 0], P0[0, 2], P0[1, 2]
+    rvec, tvec = np.array([0.01, -0.02, 0.005]), np.array([0.05, -0.01, -0.8])
+    vv, uu = np.mgrid[0:H, 0:W]
+    depth = 6.0 + 0.03 * uu + 0.05 * vv + 2.0 * np.sin(uu / 37.0) * np.cos(vv / 23.0)
+    rng = np.random.RandomState(11)
+    sets = [np.stack([rng.uniform(20, W - 20, 60), rng.uniform(10, H - 10, 60)], axis=1),
+            np.array([[100.3, 40.7], [500.2, 60.1], [320.9, 150.4], [200.5, 100.5]]),
+            np.array([[100.3, 40.7], [500.2, 60.1], [320.9, 150.4], [200.5, 100.5], [420.25, 33.5]]),
+            np.array([[100.3, 40.7], [500.2, 60.1], [320.9, 150.4]])]
+    results = []
+    for dev in (0, 1):
+        ctx = abi.Context(abi.default_params(W, H, max_batch=6, num_disparities=64, max_features=4096, pnp_device=dev))
+        ctx.set_calib(P0, P1)
+        blank = np.zeros((len(sets), H, W), dtype=np.uint8)
+        ctx.set_images(blank, blank, blank, blank)
+        ctx.compute_disparity(); ctx.compute_depth_map()    # a batch's maps exist before a caller replaces them frame by frame
+        for b, pts in enumerate(sets):
+            t1 = pts.astype(np.float32)
+            ctx.set_depth(depth, b)
+            obj, _, _ = ob.triangulate(t1, t1, depth, P0)
+            Xc = Rotation.from_rotvec(rvec).apply(obj.astype(np.float64)) + tvec
+            t2 = np.stack([fx * Xc[:, 0] / Xc[:, 2] + cx, fx * Xc[:, 1] / Xc[:, 2] + cy], axis=1)
+            t2 += np.random.RandomState(b).normal(0, 0.2, t2.shape) if b == 0 else 0.0
+            ctx.set_matches(t1, t2.astype(np.float32), b)
+        ctx.triangulate()
+        Rt = np.zeros((len(sets), 4, 4)); info = (abi.FrameInfo * len(sets))()
+        rc = ctx._L.vo_estimate_motion(ctx._h, Rt.ctypes.data_as(abi.C.c_void_p), info)
+        assert rc == -7     # VO_ERR_NOT_ENOUGH_POINTS: the three-point frame; every frame's outputs are filled all the same
+        results.append((Rt.copy(), [(i.ok, i.iters_run, i.best_inliers, i.n_object_points) for i in info]))
+        ctx.close()
+    (Rt0, i0), (Rt1, i1) = results
+    assert [x[3] for x in i0] == [60, 4, 5, 3] and [x[0] for x in i0] == [1, 1, 1, 0]
+    assert i0[1:] == i1[1:] and np.array_equal(Rt0[1:], Rt1[1:])            # no rounds: the host solved them either way
+    assert i1[0][0] == 1 and abs(i0[0][2] - i1[0][2]) <= 2
+    assert _rot_angle(Rt0[0][:3, :3], Rt1[0][:3, :3]) <= 1e-4 and np.abs(Rt0[0][:3, 3] - Rt1[0][:3, 3]).max() <= 1e-3
+    assert _rot_angle(Rt1[0][:3, :3], Rotation.from_rotvec(rvec).as_matrix()) <= 2e-3 and np.abs(Rt1[0][:3, 3] - tvec).max() <= 2e-2
