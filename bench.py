@@ -376,8 +376,11 @@ def main(argv=None):
     # batch beyond three batches; the box refuses more than 32).  The 4K and dense-tracking workloads keep a batch on one
     # stream, gain nothing from more queues (167.5 against 166, 1 553 against 1 546 frames/s) and keep 4.
     # (Under a profiler that initialises the runtime before main() the variable has to be exported in the shell instead.)
+    # A short run is mostly fill and drain, where the extra queues cost instead (20 steps: 5 483 / 5 488 frames/s with 4 queues
+    # against 5 409 / 5 368 with 8, and a lone pair takes 1.57 instead of 1.72 ms), so only runs of 100 steps or more ask for them.
     # The variable is set here whatever the environment holds (machines export HIP's default of 4); --hw-queues N chooses another.
-    queues = args.hw_queues if args.hw_queues > 0 else (max(8, 2 * args.inflight) if args.workload in ("kitti", "kitti11") else max(4, 2 * args.inflight if args.inflight > 3 else 4))
+    long_run = args.workload == "kitti11" or (args.workload == "kitti" and args.steps >= 100)
+    queues = args.hw_queues if args.hw_queues > 0 else (max(8, 2 * args.inflight) if long_run else max(4, 2 * args.inflight if args.inflight > 3 else 4))
     os.environ["GPU_MAX_HW_QUEUES"] = str(min(32, queues))
     log("[bench] GPU_MAX_HW_QUEUES=%s for %d batches in flight" % (os.environ["GPU_MAX_HW_QUEUES"], args.inflight))
 
@@ -785,7 +788,7 @@ def main(argv=None):
         whole_gbs = frame_bytes(W, H, D) * fps / world / 1e9
         config = {"workload": "%s: synthetic stereo, %dx%d, %d disparities, %d frame pairs per step per GPU, whole hot path "
                               "(SGBM-3way + FAST + circular KLT + triangulation + PnP-RANSAC)" % (args.workload, W, H, D, B),
-                  "batch": B, "batches_in_flight": nctx, "input_mode": args.mode,
+                  "batch": B, "batches_in_flight": nctx, "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]), "input_mode": args.mode,
                   "inputs": "uploaded from host memory every step" if args.upload else "resident in HBM",
                   "distinct_frames_per_rank": nframes, "windows_per_rank": nwin, "host_threads_per_rank": args.host_threads,
                   "pnp_minimal_solves": "gpu" if (not stub and p.pnp_device) else "host",
