@@ -92,7 +92,7 @@ typedef struct {
      * rule and runs the final iterative solve).  Same arithmetic in the same order; the device's hypot / acos / sin / cos differ
      * from the host's in the last bits, which a five-point solve now and then amplifies into a visibly different hypothesis
      * (3 of 199 steps of the KITTI-shape test sequence end with a few inliers more or less; poses stay within 1e-4 rad / 1e-3 m).  For rounds whose solves outrun the host (1 024 hypotheses
-     * per frame: 2.6 ms against 77 ms on 16 threads).  A round costs 1.8 ms of latency however few its solves (one thread's
+     * per frame: 2.3 ms against 77 ms on 16 threads).  A round costs 1.2 ms of latency however few its solves (one thread's
      * serial work), so at the reference's 8 hypotheses per round the host is the faster place, with 16 threads or with 2. */
     int pnp_device;           /* 0 */
 } vo_params;

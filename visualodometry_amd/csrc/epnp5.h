@@ -1,8 +1,9 @@
 // The 5-point EPnP minimal solve of cv::solvePnPRansac (reference call site Source/VOClass.cpp:531) on fixed-size arrays,
 // callable from host and device code.  Same arithmetic, in the same order, as pnp_host::epnp (pnp_host.cpp) for n = 5:
 // compiled for the host it returns that function's bits (tests/test_host_cpu.py), compiled for gfx950 it differs from it
-// only through the device's hypot / acos / sin / cos (an ulp here and there).  Nothing is allocated: the largest
-// per-call arrays are the 10 x 12 system matrix and the 12 x 12 Jacobi work matrices (3.6 KB of private memory per thread).
+// only through the device's hypot / acos / sin / cos (an ulp here and there).  Nothing is allocated: the two 12 x 12 Jacobi
+// work matrices come from the caller (private arrays, or LDS on the GPU), the 10 x 12 system matrix and the small
+// factorizations are private.
 #ifndef VO_EPNP5_H
 #define VO_EPNP5_H
 
@@ -18,6 +19,9 @@ namespace epnp5 {
 // Hestenes (one-sided Jacobi) iteration on the columns of an m x n matrix, held as n rows of length m in `a`, with the squared
 // column norms in `w` and the identity in `v` (n x n) on entry.  On return: w = singular values (descending), row i of a =
 // left singular vector i times w[i], row i of v = right singular vector i.
+// S: distance in doubles between consecutive elements of a and v (1 on the host and for private arrays; on the GPU the 12 x 12
+// matrices of a block's threads are interleaved in LDS, element e of thread t at e * S + t, which is free of bank conflicts)
+template <int S = 1>
 VO_HD void jacobi_core(double* a, int m, int n, double* v, double* w)
 {
     const double eps = DBL_EPSILON * 10;
@@ -26,9 +30,9 @@ VO_HD void jacobi_core(double* a, int m, int n, double* v, double* w)
         bool rotated = false;
         for (int i = 0; i < n - 1; i++)
             for (int j = i + 1; j < n; j++) {
-                double* ai = a + i * m; double* aj = a + j * m;
+                double* ai = a + i * m * S; double* aj = a + j * m * S;
                 double aa = w[i], bb = w[j], p = 0;
-                for (int k = 0; k < m; k++) p += ai[k] * aj[k];
+                for (int k = 0; k < m; k++) p += ai[k * S] * aj[k * S];
                 if (fabs(p) <= eps * sqrt(aa * bb)) continue;
                 p *= 2;
                 const double beta = aa - bb, gamma = hypot(p, beta);
@@ -43,25 +47,25 @@ VO_HD void jacobi_core(double* a, int m, int n, double* v, double* w)
                 }
                 aa = bb = 0;
                 for (int k = 0; k < m; k++) {
-                    const double t0 = c * ai[k] + s * aj[k];
-                    const double t1 = -s * ai[k] + c * aj[k];
-                    ai[k] = t0; aj[k] = t1;
+                    const double t0 = c * ai[k * S] + s * aj[k * S];
+                    const double t1 = -s * ai[k * S] + c * aj[k * S];
+                    ai[k * S] = t0; aj[k * S] = t1;
                     aa += t0 * t0; bb += t1 * t1;
                 }
                 w[i] = aa; w[j] = bb;
                 rotated = true;
-                double* vi = v + i * n; double* vj = v + j * n;
+                double* vi = v + i * n * S; double* vj = v + j * n * S;
                 for (int k = 0; k < n; k++) {
-                    const double t0 = c * vi[k] + s * vj[k];
-                    const double t1 = -s * vi[k] + c * vj[k];
-                    vi[k] = t0; vj[k] = t1;
+                    const double t0 = c * vi[k * S] + s * vj[k * S];
+                    const double t1 = -s * vi[k * S] + c * vj[k * S];
+                    vi[k * S] = t0; vj[k * S] = t1;
                 }
             }
         if (!rotated) break;
     }
     for (int i = 0; i < n; i++) {
         double sd = 0;
-        for (int k = 0; k < m; k++) { const double t = a[i * m + k]; sd += t * t; }
+        for (int k = 0; k < m; k++) { const double t = a[(i * m + k) * S]; sd += t * t; }
         w[i] = sqrt(sd);
     }
     for (int i = 0; i < n - 1; i++) {
@@ -69,8 +73,8 @@ VO_HD void jacobi_core(double* a, int m, int n, double* v, double* w)
         for (int k = i + 1; k < n; k++) if (w[j] < w[k]) j = k;
         if (i != j) {
             double t = w[i]; w[i] = w[j]; w[j] = t;
-            for (int k = 0; k < m; k++) { t = a[i * m + k]; a[i * m + k] = a[j * m + k]; a[j * m + k] = t; }
-            for (int k = 0; k < n; k++) { t = v[i * n + k]; v[i * n + k] = v[j * n + k]; v[j * n + k] = t; }
+            for (int k = 0; k < m; k++) { t = a[(i * m + k) * S]; a[(i * m + k) * S] = a[(j * m + k) * S]; a[(j * m + k) * S] = t; }
+            for (int k = 0; k < n; k++) { t = v[(i * n + k) * S]; v[(i * n + k) * S] = v[(j * n + k) * S]; v[(j * n + k) * S] = t; }
         }
     }
 }
@@ -227,14 +231,15 @@ VO_HD void barycentric_coordinates(Problem& e)
 }
 
 // 6 x 10 from the four right singular vectors of the smallest singular values (rows 11..8 of vt)
+template <int S = 1>
 VO_HD void build_L(const double* vt, double* L)
 {
     double dv[4][6][3];
     for (int i = 0; i < 4; i++) {
-        const double* v = vt + 12 * (11 - i);
+        const double* v = vt + 12 * (11 - i) * S;
         int a = 0, b = 1;
         for (int j = 0; j < 6; j++) {
-            for (int k = 0; k < 3; k++) dv[i][j][k] = v[3 * a + k] - v[3 * b + k];
+            for (int k = 0; k < 3; k++) dv[i][j][k] = v[(3 * a + k) * S] - v[(3 * b + k) * S];
             if (++b > 3) { a++; b = a + 1; }
         }
     }
@@ -340,13 +345,14 @@ VO_HD void refine_beta(const double* L, const double* rho, double beta[4])
 }
 
 // absolute orientation (Horn / SVD) between camera-frame and world points, then the mean reprojection error
+template <int S = 1>
 VO_HD double pose_from_beta(Problem& e, const double* vt, const double* beta, double R[3][3], double t[3])
 {
     const int n = 5;
     for (int i = 0; i < 4; i++) e.cc[i][0] = e.cc[i][1] = e.cc[i][2] = 0.0;
     for (int i = 0; i < 4; i++) {
-        const double* v = vt + 12 * (11 - i);
-        for (int j = 0; j < 4; j++) for (int k = 0; k < 3; k++) e.cc[j][k] += beta[i] * v[3 * j + k];
+        const double* v = vt + 12 * (11 - i) * S;
+        for (int j = 0; j < 4; j++) for (int k = 0; k < 3; k++) e.cc[j][k] += beta[i] * v[(3 * j + k) * S];
     }
     for (int i = 0; i < n; i++) {
         const double* a = &e.alpha[4 * i]; double* pc = &e.cam[3 * i];
@@ -388,8 +394,10 @@ VO_HD double pose_from_beta(Problem& e, const double* vt, const double* beta, do
     return acc / n;
 }
 
-// solvePnP(SOLVEPNP_EPNP) on exactly five float correspondences; K row-major 3x3
-VO_HD void solve(const vo_point3f* obj, const vo_point2f* img, const double K[9], double rvec[3], double tvec[3])
+// solvePnP(SOLVEPNP_EPNP) on exactly five float correspondences; K row-major 3x3.  a and vt: 144 doubles of work space each,
+// element e at [e * S] (the 12 x 12 Jacobi matrices; private arrays with S = 1, or a block's interleaved LDS arrays)
+template <int S>
+VO_HD void solve_ws(const vo_point3f* obj, const vo_point2f* img, const double K[9], double rvec[3], double tvec[3], double* a, double* vt)
 {
     const int n = 5;
     Problem e;
@@ -416,31 +424,31 @@ VO_HD void solve(const vo_point3f* obj, const vo_point2f* img, const double K[9]
     }
     // M^T M is symmetric: its rows are at once the columns the Jacobi iteration works on, and after the iteration the rows
     // of v, sorted by singular value, are the rows of V^T
-    double a[144], vt[144], w[12];
+    double w[12];
     for (int r = 0; r < 12; r++) {
         for (int c = 0; c < 12; c++) {
             double s = 0;
             for (int i = 0; i < 2 * n; i++) s += M[i * 12 + c] * M[i * 12 + r];
-            a[r * 12 + c] = s;
-            vt[r * 12 + c] = 0.0;
+            a[(r * 12 + c) * S] = s;
+            vt[(r * 12 + c) * S] = 0.0;
         }
-        vt[r * 12 + r] = 1.0;
+        vt[(r * 12 + r) * S] = 1.0;
     }
     for (int r = 0; r < 12; r++) {
         double sd = 0;
-        for (int k = 0; k < 12; k++) { const double t = a[r * 12 + k]; sd += t * t; }
+        for (int k = 0; k < 12; k++) { const double t = a[(r * 12 + k) * S]; sd += t * t; }
         w[r] = sd;
     }
-    jacobi_core(a, 12, 12, vt, w);
+    jacobi_core<S>(a, 12, 12, vt, w);
     double L[60], rho[6];
-    build_L(vt, L);
+    build_L<S>(vt, L);
     rho[0] = sqdist3(e.cw[0], e.cw[1]); rho[1] = sqdist3(e.cw[0], e.cw[2]); rho[2] = sqdist3(e.cw[0], e.cw[3]);
     rho[3] = sqdist3(e.cw[1], e.cw[2]); rho[4] = sqdist3(e.cw[1], e.cw[3]); rho[5] = sqdist3(e.cw[2], e.cw[3]);
     double beta[4][4], rep[4], Rs[4][3][3], ts[4][3];
     for (int k = 1; k <= 3; k++) {
         beta_start(k, L, rho, beta[k]);
         refine_beta(L, rho, beta[k]);
-        rep[k] = pose_from_beta(e, vt, beta[k], Rs[k], ts[k]);
+        rep[k] = pose_from_beta<S>(e, vt, beta[k], Rs[k], ts[k]);
     }
     int N = 1;
     if (rep[2] < rep[1]) N = 2;
@@ -448,6 +456,13 @@ VO_HD void solve(const vo_point3f* obj, const vo_point2f* img, const double K[9]
     double R[9];
     for (int i = 0; i < 3; i++) { tvec[i] = ts[N][i]; for (int j = 0; j < 3; j++) R[i * 3 + j] = Rs[N][i][j]; }
     rodrigues_from_matrix(R, rvec);
+}
+
+// the same with private work matrices
+VO_HD void solve(const vo_point3f* obj, const vo_point2f* img, const double K[9], double rvec[3], double tvec[3])
+{
+    double a[144], vt[144];
+    solve_ws<1>(obj, img, K, rvec, tvec, a, vt);
 }
 
 } // namespace epnp5

@@ -5,16 +5,21 @@
 // so a hypothesis differs from the host's only through the device's hypot / acos / sin / cos.
 #include "vo_ctx.h"
 #include "epnp5.h"
+#include <atomic>
 
 namespace {
 
 struct SolveArgs { double K[9]; int max_features, chunk, total; };
 
-__global__ __launch_bounds__(64) void epnp5_kernel(SolveArgs a, const vo_point3f* __restrict__ obj, const vo_point2f* __restrict__ img,
+#ifndef VO_EPNP_LDS
+#define VO_EPNP_LDS 1
+#endif
+constexpr int EP_T = VO_EPNP_LDS ? 32 : 64; // threads per block: the LDS form holds 2 x 144 doubles per thread (73.7 KB per 32 threads)
+__global__ __launch_bounds__(EP_T) void epnp5_kernel(SolveArgs a, const vo_point3f* __restrict__ obj, const vo_point2f* __restrict__ img,
                                                    const int* __restrict__ idx, const int* __restrict__ nh,
                                                    double* __restrict__ hyp, double* __restrict__ rt6)
 {
-    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int t = blockIdx.x * EP_T + threadIdx.x;
     if (t >= a.total) return;
     const int b = t / a.chunk;
     if (nh[b] <= 0) return; // a frame that has stopped iterating: its slots are not read
@@ -26,7 +31,14 @@ __global__ __launch_bounds__(64) void epnp5_kernel(SolveArgs a, const vo_point3f
         so[j] = obj[b * F + i]; si[j] = img[b * F + i];
     }
     double rvec[3], tvec[3], R[9];
+#if VO_EPNP_LDS
+    // the two 12 x 12 Jacobi matrices of the block's threads interleaved in LDS (element e of thread t at e * EP_T + t): a solve
+    // is one thread's serial chain through them, and LDS answers several times faster than private (scratch) memory
+    extern __shared__ double ep_lds[];
+    epnp5::solve_ws<EP_T>(so, si, a.K, rvec, tvec, ep_lds + threadIdx.x, ep_lds + 144 * EP_T + threadIdx.x);
+#else
     epnp5::solve(so, si, a.K, rvec, tvec);
+#endif
     epnp5::rodrigues_to_matrix(rvec, R);
     double* dst = hyp + (size_t)t * 12;
 #pragma unroll
@@ -46,7 +58,13 @@ int launch_pnp_solve(vo_ctx* c, int n)
     for (int k = 0; k < 9; k++) a.K[k] = K[k];
     a.max_features = c->p.max_features; a.chunk = c->p.ransac_chunk; a.total = n * c->p.ransac_chunk;
     StageTimer st_(c, VO_ST_PNP_SOLVE);
-    hipLaunchKernelGGL(epnp5_kernel, dim3((a.total + 63) / 64), dim3(64), 0, c->stream, a, c->obj, c->obj_img, c->hyp_idx, c->hyp_idx + (size_t)c->p.max_batch * c->p.ransac_chunk * 5,
+    const size_t lds = VO_EPNP_LDS ? (size_t)2 * 144 * EP_T * sizeof(double) : 0;
+    static std::atomic<int> lds_attr[64];
+    if (lds > 48 * 1024 && lds_attr[c->device & 63].load(std::memory_order_acquire) < (int)lds) {
+        VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&epnp5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_attr[c->device & 63].store((int)lds, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(epnp5_kernel, dim3((a.total + EP_T - 1) / EP_T), dim3(EP_T), lds, c->stream, a, c->obj, c->obj_img, c->hyp_idx, c->hyp_idx + (size_t)c->p.max_batch * c->p.ransac_chunk * 5,
                        c->hyp, c->hyp_rt);
     VO_HIP(c, hipGetLastError());
     return VO_OK;
