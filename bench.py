@@ -362,9 +362,14 @@ def main(argv=None):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args, argv)
     if args.batch <= 0:
-        # 42 pairs at KITTI shape: the horizontal-path kernels run one wavefront per four image rows, 94 per frame and two per SIMD,
-        # so 42 frames fill the 2048 wavefront slots of the chip almost twice over (96 %), where 16 frames leave a quarter idle
-        args.batch = 8 if args.workload == "4k" else 42
+        # Frame pairs per step.  The horizontal-path kernels run one wavefront per four image rows, 94 per KITTI-shape frame and two
+        # per SIMD, so 42 frames fill the chip's 2048 wavefront slots almost twice over (96 %), where 16 frames leave a quarter
+        # idle: that set the batch while a batch ran on one stream (5 250 frames/s at 42 against 4 790 at 16).  With the tracker
+        # beside the horizontal passes the fit matters less and larger batches amortise more of a step's fixed costs: 56 pairs
+        # give 5 985-5 995 frames/s against 5 890-5 925 at 42 over 300 steps, 5 795-5 825 against 5 540-5 575 over 20, and 5 826
+        # against 5 659 on the 11-sequence workload (32 / 48 / 63 / 64 pairs: 5 965 / 5 958 / 6 074 / 6 068 over 200 steps).
+        # Dense tracking stays at 42 (1 622 against 1 606 frames/s at 56), 4K x 256 at 8 (5.5 GB per pair in the batch).
+        args.batch = 8 if args.workload == "4k" else 42 if args.workload == "dense" else 56
     if args.inflight <= 0:
         # Three batches in flight where the GPU is the limit (a fourth only adds contention).  The 11-sequence workload has the
         # longer host part per batch (4.2 ms against 2.8 ms: its frame pools are walked in both directions and the harder pairs

@@ -25,10 +25,11 @@ timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d $out -o default --output
 # through vo_set_timing(2))
 export VO_SINGLE_STREAM=1
 timeout -s KILL 200 rocprofv3 --kernel-trace --stats -d $out -o inflight1 --output-format csv -- python3 $B $C $P --steps 10 --warmup 2 --inflight 1 > $out/inflight1.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $out -o fetch --output-format csv -- python3 $B $C --steps 3 --warmup 1 $P --inflight 1 > $out/fetch.log 2>&1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $out -o write --output-format csv -- python3 $B $C --steps 3 --warmup 1 $P --inflight 1 > $out/write.log 2>&1
+# the counter passes stay at 42 pairs per launch, the batch profiles/traffic.json and valu.json record (bench.py scales them)
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $out -o fetch --output-format csv -- python3 $B $C --batch 42 --steps 3 --warmup 1 $P --inflight 1 > $out/fetch.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $out -o write --output-format csv -- python3 $B $C --batch 42 --steps 3 --warmup 1 $P --inflight 1 > $out/write.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
-    -d $out -o sq --output-format csv -- python3 $B $C --steps 3 --warmup 1 $P --inflight 1 > $out/sq.log 2>&1
+    -d $out -o sq --output-format csv -- python3 $B $C --batch 42 --steps 3 --warmup 1 $P --inflight 1 > $out/sq.log 2>&1
 unset VO_SINGLE_STREAM GPU_MAX_HW_QUEUES   # the dense-tracking runs keep the default 4 queues
 # the dense-tracking configuration: its line and its kernel statistics
 timeout -k 10 300 python3 $B --workload dense --steps 40 $C > $out/bench_dense.json 2> $out/bench_dense.err
