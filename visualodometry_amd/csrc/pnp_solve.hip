@@ -11,10 +11,9 @@ namespace {
 
 struct SolveArgs { double K[9]; int max_features, chunk, total; };
 
-#ifndef VO_EPNP_LDS
-#define VO_EPNP_LDS 1
-#endif
-constexpr int EP_T = VO_EPNP_LDS ? 32 : 64; // threads per block: the LDS form holds 2 x 144 doubles per thread (73.7 KB per 32 threads)
+// threads per block: a thread's two 12 x 12 Jacobi work matrices live in LDS (2 x 144 doubles: 73.7 KB per 32 threads, two
+// blocks per CU); with the matrices in private memory instead a round took 1.8 instead of 1.15 ms
+constexpr int EP_T = 32;
 __global__ __launch_bounds__(EP_T) void epnp5_kernel(SolveArgs a, const vo_point3f* __restrict__ obj, const vo_point2f* __restrict__ img,
                                                    const int* __restrict__ idx, const int* __restrict__ nh,
                                                    double* __restrict__ hyp, double* __restrict__ rt6)
@@ -31,14 +30,10 @@ __global__ __launch_bounds__(EP_T) void epnp5_kernel(SolveArgs a, const vo_point
         so[j] = obj[b * F + i]; si[j] = img[b * F + i];
     }
     double rvec[3], tvec[3], R[9];
-#if VO_EPNP_LDS
     // the two 12 x 12 Jacobi matrices of the block's threads interleaved in LDS (element e of thread t at e * EP_T + t): a solve
     // is one thread's serial chain through them, and LDS answers several times faster than private (scratch) memory
     extern __shared__ double ep_lds[];
     epnp5::solve_ws<EP_T>(so, si, a.K, rvec, tvec, ep_lds + threadIdx.x, ep_lds + 144 * EP_T + threadIdx.x);
-#else
-    epnp5::solve(so, si, a.K, rvec, tvec);
-#endif
     epnp5::rodrigues_to_matrix(rvec, R);
     double* dst = hyp + (size_t)t * 12;
 #pragma unroll
@@ -58,7 +53,7 @@ int launch_pnp_solve(vo_ctx* c, int n)
     for (int k = 0; k < 9; k++) a.K[k] = K[k];
     a.max_features = c->p.max_features; a.chunk = c->p.ransac_chunk; a.total = n * c->p.ransac_chunk;
     StageTimer st_(c, VO_ST_PNP_SOLVE);
-    const size_t lds = VO_EPNP_LDS ? (size_t)2 * 144 * EP_T * sizeof(double) : 0;
+    const size_t lds = (size_t)2 * 144 * EP_T * sizeof(double);
     static std::atomic<int> lds_attr[64];
     if (lds > 48 * 1024 && lds_attr[c->device & 63].load(std::memory_order_acquire) < (int)lds) {
         VO_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&epnp5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
