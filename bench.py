@@ -309,7 +309,7 @@ def parse_args(argv):
     ap.add_argument("--steps", type=int, default=300,
                     help="timed steps (default 300, about 2.3 s at KITTI shape: the fill and drain of the pipeline are 3 %% of 50 steps)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=0, help="frame pairs per step (default: 42 at KITTI shape, 8 at 4K)")
+    ap.add_argument("--batch", type=int, default=0, help="frame pairs per step (default: 56 at KITTI shape, 42 for dense tracking, 8 at 4K)")
     ap.add_argument("--workload", default="kitti", choices=["kitti", "4k", "kitti11", "dense"])
     ap.add_argument("--frames", type=int, default=0,
                     help="consecutive frames rendered per rank and kept in HBM (default: 200 at KITTI shape, the whole sequence of "
