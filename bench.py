@@ -320,7 +320,7 @@ def parse_args(argv):
                     help="frame pairs of the CPU baseline's sample (default: 48 at KITTI shape, about 10 s on 16 threads; 1 at 4K)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0)
-    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0: 8 at KITTI shape, else 4; at most 32)")
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (0: 8 for KITTI-shape runs of 100 steps and more and for kitti11, else 4; at most 32)")
     ap.add_argument("--pnp-device", type=int, default=None, choices=(0, 1),
                     help="RANSAC minimal solves on the host (0) or on the GPU (1); default: GPU for the dense workload, host otherwise")
     ap.add_argument("--inflight", type=int, default=0,
